@@ -1,0 +1,226 @@
+/*
+ * clipfs.h -- C ABI of libclipfs_hip.so: the MI355X (gfx950) engine behind the
+ * reference's Python API for the CLIP few-shot hot path.
+ *
+ * The reference (Dokumushikun/jittor-clip-fewshot) has NO FFI / plugin layer:
+ * every op below is executed today by Jittor-generated CUDA kernels reached from
+ * Python.  Each entry point cites the reference Python site
+ * whose arithmetic it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named h_*; tensors are fp32,
+ *     row-major, densely packed unless a leading dimension is given;
+ *   - activations are token-major: row m = b * L + l  (the reference is
+ *     sequence-first [L, N, d]; only the memory order differs, not the values);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - return value: 0 = ok, CLIPFS_EINVAL = bad argument (nothing launched),
+ *     otherwise 1000 + hipError_t of the failed launch;
+ *   - no entry point allocates, frees, synchronises or keeps global state: all
+ *     buffers (workspaces included) are owned by the caller (PyTorch-ROCm tensors).
+ */
+#ifndef CLIPFS_H
+#define CLIPFS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLIPFS_OK 0
+#define CLIPFS_EINVAL 1
+#define CLIPFS_HIPERR_BASE 1000
+
+#define CLIPFS_ABI_VERSION 1
+int clipfs_abi_version(void);
+/* human readable description of the last CLIPFS_EINVAL on this thread */
+const char* clipfs_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM --
+ * C[M,N] = epilogue( alpha * A[M,K] * B[N,K]^T )      fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ * Replaces every jittor.nn.linear / matmul on the path: packed QKV (jclip/mha.py:140),
+ * LinearLoRA (lora_train_vlp.py:286-306), out_proj (mha.py:461), MLP (jclip/model.py:34-39),
+ * patch-embed conv (model.py:87-91,105), visual.proj / text_projection (model.py:124,213-214),
+ * cosine logits (lora_train_vlp.py:995), and their input-gradients.
+ * Epilogue, in this order (each part optional):
+ *     v  = alpha * acc + bias[n]
+ *     v += lora_scale * sum_j lora_t[m, seg*r + j] * lora_b[n, j]      seg = n / lora_seg_width
+ *     if act == 1:  (aux_out[m,n] = v);  v = v * sigmoid(1.702 v)        QuickGELU, model.py:24-27
+ *     if act == 2:  v = v * dQuickGELU(aux_in[m,n])                      backward of act 1
+ *     v += residual[rm, n]                                               model.py:60-61
+ *     C[out_row(m), n] = v
+ * a_mode 0: A is row-major [M,K] with leading dimension lda.
+ * a_mode 1: A is an NCHW image batch [B,3,R,R]; row m = (b, py, px) patch, column
+ *           k = (c, ky, kx)  (im2col on the fly, kernel = stride = patch).  Then
+ *           out_row(m) = b*out_tokens + 1 + p and residual row rm = 1 + p  (p = m % P):
+ *           class-token slot skipped, positional embedding added (model.py:105-114).
+ */
+typedef struct clipfs_gemm_args {
+  const float* A;
+  const float* B;          /* [N,K] row-major, ldb */
+  float* C;                /* [*,N] row-major, ldc */
+  int M, N, K;
+  int lda, ldb, ldc;
+  float alpha;
+  const float* bias;       /* [N] or NULL */
+  const float* residual;   /* [*,N] (ld = ldres) or NULL */
+  int ldres;
+  int act;                 /* 0 none, 1 QuickGELU, 2 multiply by dQuickGELU(aux_in) */
+  float* aux_out;          /* act 1: pre-activation copy (ld = ldc) or NULL */
+  const float* aux_in;     /* act 2: saved pre-activation (ld = ldc) */
+  const float* lora_t;     /* [M, lora_nseg * lora_r] or NULL */
+  const float* lora_b;     /* [N, lora_r] */
+  int lora_r, lora_nseg, lora_seg_width;
+  float lora_scale;
+  int a_mode;              /* 0 dense, 1 patch im2col */
+  int img_res, patch, out_tokens; /* a_mode 1 */
+} clipfs_gemm_args;
+int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------- LayerNorm --
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim (biased var).
+ * Replaces jittor nn.LayerNorm, jclip/model.py:17-21,115,121,209.
+ * `x` rows are read with stride ldx (lets ln_post read the class-token rows in place).
+ * mean/rstd (each [rows]) may be NULL (inference). */
+int clipfs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y,
+                         float* mean, float* rstd, int rows, int width, float eps, void* stream);
+/* dx = dres + LN'(dy)   (dres may be NULL); gamma frozen: no dgamma/dbeta. */
+int clipfs_layernorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* mean,
+                         const float* rstd, const float* dres, float* dx, int lddx, int rows, int width,
+                         void* stream);
+
+/* ------------------------------------------------------------- attention --
+ * qkv [B*L, 3*d] (q | k | v, head h at columns h*64..), out [B*L, d] heads merged.
+ * out = softmax(q k^T / sqrt(64) + causal mask) v per (b, head), head_dim = 64.
+ * Replaces scaled_dot_product_attention + reshapes + permute(2,0,1,3):
+ * jclip/mha.py:55-83,439-458 and lora_train_vlp.py:339-367,492-501.
+ * Scores/probabilities never leave the CU (reference: [N*H,L,L] round trip in HBM). */
+int clipfs_attention_fwd(const float* qkv, float* out, int batch, int seq, int heads, int causal, void* stream);
+/* dqkv from dout, recomputing the probabilities from qkv. */
+int clipfs_attention_bwd(const float* qkv, const float* dout, float* dqkv, int batch, int seq, int heads,
+                         int causal, void* stream);
+
+/* ------------------------------------------------------------------ LoRA --
+ * t[m, s*r + j] = sum_k drop_s(x)[m,k] * A[s*r + j, k]       (the "down" half of
+ * lora_train_vlp.py:302: x @ (B@A)^T == (x @ A^T) @ B^T; the reference materialises B@A).
+ * drop_s = Philox dropout of nn.Dropout(p) (:298-299), one independent stream per
+ * segment s: stream id = stream_base + s, element (m,k) as documented in DESIGN.md;
+ * p = 0 or seed == 0 disables dropout.  seg_mask bit s = 0 leaves t[:, s*r..] = 0. */
+int clipfs_lora_down(const float* x, const float* A, float* t, int rows, int width, int r, int nseg,
+                     unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, void* stream);
+/* Backward of the adapter pair for one linear with nseg stacked segments:
+ *   dt[m, s*r+j]  = scale * sum_n dy[m, s*segw + n] * B[s*segw + n, j]
+ *   dB[s*segw+n,j] += scale * sum_m dy[m, s*segw+n] * t[m, s*r+j]
+ *   dA[s*r+j, k]  += sum_m dt[m, s*r+j] * drop_s(x)[m,k]
+ *   dx[m,k]       += sum_{s,j} dt[m, s*r+j] * A[s*r+j,k] * dropscale_s(m,k)   (if dx != NULL)
+ * work: caller scratch, >= clipfs_lora_bwd_work_floats(...) floats. */
+size_t clipfs_lora_bwd_work_floats(int rows, int width, int r, int nseg);
+int clipfs_lora_bwd(const float* dy, const float* x, const float* t, const float* A, const float* B,
+                    float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
+                    int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
+                    float* work, void* stream);
+
+/* --------------------------------------------------------- token assembly --
+ * vit: x[b,0,:] = class_embedding + pos[0]; x[b, 1+P+i, :] = vpt[i]  (jclip/model.py:109-114,
+ * jclip/model1.py:192-194).  Patch rows are written by the patch GEMM epilogue. */
+int clipfs_vit_fill_special(float* x, const float* class_emb, const float* pos, const float* vpt, int batch,
+                            int tokens, int n_patch, int n_vpt, int width, void* stream);
+/* text: x[c,l,:] = (ctx row if 1 <= l <= n_ctx and ctx != NULL else table[ids[c,l]]) + pos[l]
+ * (jclip/model.py:203-205; slow_pace.py:185-199,838). */
+int clipfs_text_embed(const int64_t* ids, const float* table, const float* pos, const float* ctx, int n_ctx,
+                      float* x, int n, int seq, int width, void* stream);
+/* dctx[i,:] = sum_c dx[c, 1+i, :]  (gradient of the shared prompt tokens). */
+int clipfs_text_ctx_grad(const float* dx, float* dctx, int n, int seq, int width, int n_ctx, void* stream);
+/* out[c,:] = x[c*seq + argmax_l ids[c,l], :]   (EOT row, jclip/model.py:213-214) ; idx_out optional */
+int clipfs_gather_eot(const float* x, const int64_t* ids, float* out, int32_t* idx_out, int n, int seq,
+                      int width, void* stream);
+/* scatter-add of the above: dx[c*seq + idx[c], :] = dy[c,:], all other rows zero */
+int clipfs_scatter_rows(const float* dy, const int32_t* idx, float* dx, int n, int seq, int width, void* stream);
+
+/* ---------------------------------------------------------- head / loss --
+ * y = x / ||x||_2 per row; inv_norm[row] saved (may be NULL).  jclip/model.py:222-224. */
+int clipfs_l2norm_fwd(const float* x, float* y, float* inv_norm, int rows, int width, void* stream);
+/* dx = inv_norm * (dy - y * <dy,y>) */
+int clipfs_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int rows, int width,
+                      void* stream);
+/* per class: normalise each template embedding, mean, normalise (lora_train_vlp.py:978-990 /
+ * clip_classifier :647-666).  emb [C*t, d] (class major), out [C, d]. */
+int clipfs_class_mean_fwd(const float* emb, float* out, int classes, int templates, int width, void* stream);
+int clipfs_class_mean_bwd(const float* emb, const float* dout, float* demb, int classes, int templates, int width,
+                          void* stream);
+/* mean softmax cross entropy + dlogits (= (softmax - onehot) / rows * grad_scale);
+ * loss_rows [2*rows] scratch: per-sample losses, then per-row hit flags; loss_sum [1] = sum of the
+ * per-sample losses (fixed summation order).  lora_train_vlp.py:997.
+ * correct [1] (may be NULL) counts argmax == target (cls_acc :638-644). */
+int clipfs_cross_entropy(const float* logits, const int64_t* target, float* dlogits, float* loss_rows,
+                         float* loss_sum, int32_t* correct, int rows, int classes, float grad_scale,
+                         void* stream);
+/* top-k labels per row, ties broken towards the smaller class index (cls_acc :639, test.py:1738) */
+int clipfs_topk(const float* logits, int32_t* labels, int rows, int classes, int k, void* stream);
+/* Channel_LP (slow_pace.py:1195-1206): y = (scale1*x + bias1) W^T + b via clipfs_gemm_nt after this
+ * affine; logit_normalize (:1276-1280): (z - rowmean)/std_all, std unbiased clamped at 1e-6.
+ * work: >= 2 floats. */
+int clipfs_channel_affine(const float* x, const float* scale1, const float* bias1, float* y, int rows,
+                          int width, void* stream);
+int clipfs_logit_normalize(const float* z, float* out, float* work, int rows, int classes, void* stream);
+
+/* ------------------------------------------------------------- optimiser --
+ * jittor.optim.AdamW.step (lora_train_vlp.py:946,1002): p *= 1 - lr*wd; m,v update;
+ * p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  One launch over the flat LoRA+prompt buffer. */
+int clipfs_adamw(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+/* -------------------------------------------------------------------- MTA --
+ * solve_mta (lora_train_vlp.py:742-811; slow_pace.py:1363-1433), one workgroup per image.
+ * feats [n_img, V, d] unit rows (row 0 = centre view), text [C, d] (unit rows; the reference
+ * passes its transpose [d, C]).  mode_out [n_img, d], logits_out [n_img, C] = 100 * mode . text
+ * (either may be NULL).  work: >= clipfs_mta_work_floats floats.  views >= 5 (k = int(0.3 (V-1)) >= 1).
+ * The diagonal of cdist is clamped at 0 before the sqrt (deviation from :740). */
+size_t clipfs_mta_work_floats(int n_img, int views, int width, int classes);
+int clipfs_mta(const float* feats, const float* text, float* mode_out, float* logits_out, float* work,
+               int n_img, int views, int width, int classes, void* stream);
+
+/* --------------------------------------------------------- tower drivers --
+ * C++ sequencing of the kernels above for one transformer tower, so that one call
+ * from Python enqueues a whole forward or backward (no per-kernel interpreter cost).
+ * Replaces Transformer / ResidualAttentionBlock / VisionTransformer.execute and
+ * CLIP.encode_text (jclip/model.py:42-126,202-215), PlainMultiheadAttentionLoRA
+ * (lora_train_vlp.py:431-506) and their Jittor autograd. */
+typedef struct clipfs_block {
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  const float *w_qkv, *b_qkv, *w_qkv_t; /* [3d,d], [3d], transposed copy [d,3d] for dgrad */
+  const float *w_o, *b_o, *w_o_t;       /* [d,d] */
+  const float *w_fc, *b_fc, *w_fc_t;    /* [4d,d], [4d], [d,4d] */
+  const float *w_pr, *b_pr, *w_pr_t;    /* [d,4d], [d], [4d,d] */
+  /* LoRA on q,k,v (stacked: A [3r,d], B [3d,r]) and on the out projection (A [r,d], B [d,r]) */
+  const float *lora_a_qkv, *lora_b_qkv, *lora_a_o, *lora_b_o;
+  float *g_lora_a_qkv, *g_lora_b_qkv, *g_lora_a_o, *g_lora_b_o; /* gradient slots (accumulated into) */
+  unsigned lora_mask;                   /* bit0 q, bit1 k, bit2 v, bit3 o */
+} clipfs_block;
+
+typedef struct clipfs_tower {
+  int width, heads, layers, seq, causal;
+  int lora_r;
+  float lora_scale, lora_dropout;
+  uint64_t dropout_seed;    /* 0 = no dropout (eval) */
+  uint32_t dropout_stream0; /* stream id of layer 0 segment 0; layer l uses stream0 + 4*l + s */
+  const clipfs_block* blocks; /* HOST array [layers] of device pointers */
+} clipfs_tower;
+
+/* floats needed per tower call for saved activations / scratch */
+size_t clipfs_tower_saved_floats(const clipfs_tower* t, int batch);
+size_t clipfs_tower_scratch_floats(const clipfs_tower* t, int batch);
+/* x [batch*seq, width] in/out (residual stream, updated in place).  saved == NULL: inference
+ * (nothing kept); else activations for clipfs_tower_bwd are written to `saved`. */
+int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, float* scratch, void* stream);
+/* dx [batch*seq, width] in/out: gradient wrt the tower output on entry, wrt its input on exit.
+ * stop_at_input != 0: the gradient wrt the tower input is not needed (image tower without VPT:
+ * block 0's LN1 backward and q/k/v dgrad are skipped). */
+int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, const float* saved, float* scratch,
+                     int stop_at_input, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPFS_H */

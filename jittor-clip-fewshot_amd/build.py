@@ -1,0 +1,59 @@
+"""Builds libclipfs_hip.so (gfx950) in-tree with hipcc.  Usage: python build.py [--force]
+
+The library is the product's only compute path: the Python host side (clipfs/_lib.py) refuses to run
+without it.  Object files are cached under csrc/build/ and rebuilt when a source or header changes.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+OUT = os.path.join(HERE, "clipfs", "libclipfs_hip.so")
+SOURCES = ["common.hip", "gemm.hip", "norm.hip", "attention.hip", "lora.hip", "elem.hip", "mta.hip", "tower.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-Wall",
+         "-Wno-unused-function", "-ffp-contract=off"]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "clipfs.h")]
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs, jobs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, "build", s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + headers):
+            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _newer(OUT, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,267 @@
+"""Tensor-level wrappers over the C ABI (include/clipfs.h).  PyTorch is used only to own device
+memory and streams; every function here enqueues hand-written HIP kernels on the current stream.
+All tensors must be contiguous fp32 CUDA(ROCm) tensors unless stated otherwise."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "clipfs ops need device tensors (there is no CPU path)"
+    return t.data_ptr()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
+            act: int = 0, aux_out=None, aux_in=None, alpha: float = 1.0, lora_t=None, lora_b=None,
+            lora_seg_width: int = 0, lora_scale: float = 0.0) -> torch.Tensor:
+    """out = epi(alpha * a @ b.T); a [M,K], b [N,K]."""
+    _f32(a), _f32(b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    g = GemmArgs()
+    g.A, g.B, g.C = _p(a), _p(b), _p(out)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = K, K, N
+    g.alpha = alpha
+    g.bias = _p(bias)
+    g.residual = _p(residual)
+    g.ldres = N
+    g.act = act
+    g.aux_out = _p(aux_out)
+    g.aux_in = _p(aux_in)
+    if lora_t is not None:
+        r = lora_b.shape[1]
+        g.lora_t, g.lora_b = _p(_f32(lora_t)), _p(_f32(lora_b))
+        g.lora_r = r
+        g.lora_nseg = lora_t.shape[1] // r
+        g.lora_seg_width = lora_seg_width or N
+        g.lora_scale = lora_scale
+    check(_lib.load().clipfs_gemm_nt(C.byref(g), _stream()), "gemm_nt")
+    return out
+
+
+def patch_embed(images: torch.Tensor, conv_w: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, tokens: int) -> None:
+    """x[b, 1+p, :] = conv(images)[b, :, p] + pos[1+p]  (im2col-free GEMM on the NCHW batch)."""
+    _f32(images), _f32(conv_w), _f32(pos), _f32(x)
+    B, ch, R, _ = images.shape
+    width, _, ps, _ = conv_w.shape
+    assert ch == 3
+    P = (R // ps) ** 2
+    g = GemmArgs()
+    g.A, g.B, g.C = _p(images), _p(conv_w), _p(x)
+    g.M, g.N, g.K = B * P, width, 3 * ps * ps
+    g.lda, g.ldb, g.ldc = 0, 3 * ps * ps, width
+    g.alpha = 1.0
+    g.residual = _p(pos)
+    g.ldres = width
+    g.a_mode = 1
+    g.img_res, g.patch, g.out_tokens = R, ps, tokens
+    check(_lib.load().clipfs_gemm_nt(C.byref(g), _stream()), "patch_embed")
+
+
+def layernorm_fwd(x, gamma, beta, *, ldx=None, rows=None, save_stats=False, eps=1e-5):
+    width = gamma.numel()
+    if rows is None:
+        rows = x.numel() // width
+    ldx = ldx or width
+    y = torch.empty(rows, width, device=x.device, dtype=torch.float32)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(_lib.load().clipfs_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, width,
+                                           eps, _stream()), "layernorm_fwd")
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, *, ldx=None, dres=None, dx=None, lddx=None):
+    width = gamma.numel()
+    rows = dy.numel() // width
+    ldx = ldx or width
+    lddx = lddx or width
+    if dx is None:
+        dx = torch.empty(rows, width, device=dy.device, dtype=torch.float32)
+    check(_lib.load().clipfs_layernorm_bwd(_p(dy), _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), lddx,
+                                           rows, width, _stream()), "layernorm_bwd")
+    return dx
+
+
+def attention_fwd(qkv, batch, seq, heads, causal):
+    out = torch.empty(batch * seq, heads * 64, device=qkv.device, dtype=torch.float32)
+    check(_lib.load().clipfs_attention_fwd(_p(_f32(qkv)), _p(out), batch, seq, heads, int(causal), _stream()),
+          "attention_fwd")
+    return out
+
+
+def attention_bwd(qkv, dout, batch, seq, heads, causal):
+    dqkv = torch.empty_like(qkv)
+    check(_lib.load().clipfs_attention_bwd(_p(_f32(qkv)), _p(_f32(dout)), _p(dqkv), batch, seq, heads, int(causal),
+                                           _stream()), "attention_bwd")
+    return dqkv
+
+
+def lora_down(x, A, r, nseg, seg_mask=None, p=0.0, seed=0, stream_base=0):
+    rows, width = x.shape
+    t = torch.empty(rows, nseg * r, device=x.device, dtype=torch.float32)
+    if seg_mask is None:
+        seg_mask = (1 << nseg) - 1
+    check(_lib.load().clipfs_lora_down(_p(_f32(x)), _p(_f32(A)), _p(t), rows, width, r, nseg, seg_mask, p, seed,
+                                       stream_base, _stream()), "lora_down")
+    return t
+
+
+def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_base=0, seg_mask=None):
+    rows, width = x.shape
+    nseg = dy.shape[1] // width
+    r = B.shape[1]
+    if seg_mask is None:
+        seg_mask = (1 << nseg) - 1
+    lib = _lib.load()
+    nwork = lib.clipfs_lora_bwd_work_floats(rows, width, r, nseg)
+    work = torch.empty(nwork, device=x.device, dtype=torch.float32)
+    dt = torch.empty(rows, nseg * r, device=x.device, dtype=torch.float32)
+    check(lib.clipfs_lora_bwd(_p(_f32(dy)), _p(_f32(x)), _p(_f32(t)), _p(_f32(A)), _p(_f32(B)), _p(dt), _p(dA),
+                              _p(dB), _p(dx), rows, width, width, r, nseg, seg_mask, scale, p, seed, stream_base,
+                              _p(work), _stream()), "lora_bwd")
+    return dt
+
+
+def vit_fill_special(x, class_emb, pos, vpt, batch, tokens, n_patch):
+    n_vpt = 0 if vpt is None else vpt.shape[0]
+    check(_lib.load().clipfs_vit_fill_special(_p(x), _p(class_emb), _p(pos), _p(vpt), batch, tokens, n_patch, n_vpt,
+                                              class_emb.numel(), _stream()), "vit_fill_special")
+
+
+def text_embed(ids, table, pos, ctx=None):
+    n, seq = ids.shape
+    width = table.shape[1]
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    x = torch.empty(n * seq, width, device=table.device, dtype=torch.float32)
+    n_ctx = 0 if ctx is None else ctx.shape[0]
+    check(_lib.load().clipfs_text_embed(_p(ids), _p(table), _p(pos), _p(ctx), n_ctx, _p(x), n, seq, width, _stream()),
+          "text_embed")
+    return x
+
+
+def text_ctx_grad(dx, dctx, n, seq):
+    n_ctx, width = dctx.shape
+    check(_lib.load().clipfs_text_ctx_grad(_p(dx), _p(dctx), n, seq, width, n_ctx, _stream()), "text_ctx_grad")
+
+
+def gather_eot(x, ids):
+    n, seq = ids.shape
+    width = x.shape[-1]
+    out = torch.empty(n, width, device=x.device, dtype=torch.float32)
+    idx = torch.empty(n, device=x.device, dtype=torch.int32)
+    check(_lib.load().clipfs_gather_eot(_p(x), _p(ids), _p(out), _p(idx), n, seq, width, _stream()), "gather_eot")
+    return out, idx
+
+
+def scatter_rows(dy, idx, seq, out=None):
+    n, width = dy.shape
+    dx = out if out is not None else torch.empty(n * seq, width, device=dy.device, dtype=torch.float32)
+    check(_lib.load().clipfs_scatter_rows(_p(_f32(dy)), _p(idx), _p(dx), n, seq, width, _stream()), "scatter_rows")
+    return dx
+
+
+def l2norm_fwd(x, save_inv=False):
+    rows, width = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty(rows, device=x.device, dtype=torch.float32) if save_inv else None
+    check(_lib.load().clipfs_l2norm_fwd(_p(_f32(x)), _p(y), _p(inv), rows, width, _stream()), "l2norm_fwd")
+    return (y, inv) if save_inv else y
+
+
+def l2norm_bwd(dy, y, inv):
+    rows, width = y.shape
+    dx = torch.empty_like(y)
+    check(_lib.load().clipfs_l2norm_bwd(_p(_f32(dy)), _p(y), _p(inv), _p(dx), rows, width, _stream()), "l2norm_bwd")
+    return dx
+
+
+def class_mean_fwd(emb, classes, templates):
+    width = emb.shape[1]
+    out = torch.empty(classes, width, device=emb.device, dtype=torch.float32)
+    check(_lib.load().clipfs_class_mean_fwd(_p(_f32(emb)), _p(out), classes, templates, width, _stream()),
+          "class_mean_fwd")
+    return out
+
+
+def class_mean_bwd(emb, dout, classes, templates):
+    demb = torch.empty_like(emb)
+    check(_lib.load().clipfs_class_mean_bwd(_p(_f32(emb)), _p(_f32(dout)), _p(demb), classes, templates, emb.shape[1],
+                                            _stream()), "class_mean_bwd")
+    return demb
+
+
+def cross_entropy(logits, target, want_grad=True, grad_scale=1.0):
+    """returns (loss_sum [1], dlogits or None, correct [1] int32)"""
+    rows, classes = logits.shape
+    assert target.dtype == torch.int64
+    dl = torch.empty_like(logits) if want_grad else None
+    loss_rows = torch.empty(2 * rows, device=logits.device, dtype=torch.float32)
+    loss_sum = torch.empty(1, device=logits.device, dtype=torch.float32)
+    correct = torch.empty(1, device=logits.device, dtype=torch.int32)
+    check(_lib.load().clipfs_cross_entropy(_p(_f32(logits)), _p(target), _p(dl), _p(loss_rows), _p(loss_sum),
+                                           _p(correct), rows, classes, grad_scale, _stream()), "cross_entropy")
+    return loss_sum, dl, correct
+
+
+def topk(logits, k):
+    rows, classes = logits.shape
+    labels = torch.empty(rows, k, device=logits.device, dtype=torch.int32)
+    check(_lib.load().clipfs_topk(_p(_f32(logits)), _p(labels), rows, classes, k, _stream()), "topk")
+    return labels
+
+
+def channel_affine(x, scale1, bias1):
+    y = torch.empty_like(x)
+    check(_lib.load().clipfs_channel_affine(_p(_f32(x)), _p(scale1), _p(bias1), _p(y), x.shape[0], x.shape[1],
+                                            _stream()), "channel_affine")
+    return y
+
+
+def logit_normalize(z):
+    out = torch.empty_like(z)
+    work = torch.empty(2, device=z.device, dtype=torch.float32)
+    check(_lib.load().clipfs_logit_normalize(_p(_f32(z)), _p(out), _p(work), z.shape[0], z.shape[1], _stream()),
+          "logit_normalize")
+    return out
+
+
+def adamw(p, g, m, v, step, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    check(_lib.load().clipfs_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), step, lr, betas[0], betas[1], eps,
+                                   weight_decay, grad_scale, _stream()), "adamw")
+
+
+def mta(feats, text, want_mode=True, want_logits=True):
+    """feats [n_img, V, d] unit rows, text [C, d] unit rows -> (mode [n_img,d], logits [n_img,C])"""
+    n_img, V, d = feats.shape
+    Cn = text.shape[0]
+    lib = _lib.load()
+    work = torch.empty(lib.clipfs_mta_work_floats(n_img, V, d, Cn), device=feats.device, dtype=torch.float32)
+    mode = torch.empty(n_img, d, device=feats.device, dtype=torch.float32) if want_mode else None
+    logits = torch.empty(n_img, Cn, device=feats.device, dtype=torch.float32) if want_logits else None
+    check(lib.clipfs_mta(_p(_f32(feats)), _p(_f32(text)), _p(mode), _p(logits), _p(work), n_img, V, d, Cn, _stream()),
+          "mta")
+    return mode, logits

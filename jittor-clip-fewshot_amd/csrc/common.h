@@ -1,0 +1,89 @@
+// Shared helpers for the clipfs HIP sources (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "clipfs.h"
+
+namespace clipfs {
+
+void set_error(const char* fmt, ...);
+
+#define CLIPFS_REQUIRE(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      ::clipfs::set_error(__VA_ARGS__);      \
+      return CLIPFS_EINVAL;                  \
+    }                                        \
+  } while (0)
+
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("kernel launch failed: %s", hipGetErrorString(e));
+    return CLIPFS_HIPERR_BASE + (int)e;
+  }
+  return CLIPFS_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define CLIPFS_CHECK(expr)          \
+  do {                              \
+    int _rc = (expr);               \
+    if (_rc != CLIPFS_OK) return _rc; \
+  } while (0)
+
+// ---- wave64 reductions (cross-lane shuffles; no LDS) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// ---- Philox4x32-10 dropout stream (bit-identical to oracle/clip_oracle.py:dropout_keep_mask) ----
+// element (row, col): counter = (col / 4, row, stream, 0), key = (seed_lo, seed_hi), word col % 4.
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0;
+    c1 = lo1;
+    c2 = n2;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return {c0, c1, c2, c3};
+}
+__device__ __forceinline__ uint32_t dropout_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
+// multipliers (0 or inv_keep) for the 4 consecutive columns starting at col4*4 of `row`
+__device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint32_t stream, uint32_t row, uint32_t col4,
+                                                 uint32_t thr, float inv_keep) {
+  u32x4 r = philox4x32_10(col4, row, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return make_float4(r.x >= thr ? inv_keep : 0.f, r.y >= thr ? inv_keep : 0.f, r.z >= thr ? inv_keep : 0.f,
+                     r.w >= thr ? inv_keep : 0.f);
+}
+
+__device__ __forceinline__ float quick_gelu(float u) { return u / (1.f + __expf(-1.702f * u)); }
+__device__ __forceinline__ float quick_gelu_grad(float u) {
+  const float s = 1.f / (1.f + __expf(-1.702f * u));
+  return s * (1.f + 1.702f * u * (1.f - s));
+}
+
+}  // namespace clipfs

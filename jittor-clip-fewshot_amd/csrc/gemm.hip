@@ -1,0 +1,272 @@
+// fp32 "NT" GEMM on the CDNA4 matrix cores:  C[M,N] = epi( alpha * A[M,K] * B[N,K]^T ).
+//
+// v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain) -- the only MFMA that meets the
+// 1e-3-on-100x-cosine-logits budget of the north star (SURVEY.md section 7 "hard parts").
+//
+// Block tile BM x BN x 32, 256 threads = 4 waves (2 x 2), wave tile (BM/2) x (BN/2) made of
+// 32x32 MFMA tiles.  Both operands are K-contiguous in memory, so a staging thread moves 16-byte
+// K-chunks: global -> registers (issued one K-step ahead) -> LDS (double buffered, one barrier
+// per K-step).  LDS image per operand: [rows][32 floats] with the 16-byte chunk index XOR-swizzled
+// by (row >> 1) & 7, which makes both the ds_write_b128 of the staging pass and the ds_read_b128 of
+// the fragment reads bank-conflict free (read groups are 16 lanes of distinct rows; MI355X_MICROARCH
+// "LDS").  A lane's 4 consecutive k values feed 4 successive MFMAs: MFMA e of k-group q multiplies
+// k = 8q+e (lanes 0-31) and k = 8q+4+e (lanes 32-63) -- any pairing is legal as long as A and B agree.
+//
+// Ragged M and N are handled by clamping the staged row index and predicating the stores; a K tail
+// (K % 32 != 0) is zero filled.  Epilogue order is documented in include/clipfs.h.
+#include "common.h"
+
+namespace clipfs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+  clipfs_gemm_args a;
+  int n_blocks_n;  // number of BN-wide column blocks
+  int patches;     // a_mode 1: patches per image (G*G)
+  int grid_g;      // a_mode 1: patches per side
+};
+
+constexpr int BK = 32;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TM = BM / 64;            // 32x32 tiles per wave along M
+  constexpr int TN = BN / 64;            // ... along N
+  constexpr int A_CHUNKS = BM * 8 / 256; // 16-byte chunks staged per thread
+  constexpr int B_CHUNKS = BN * 8 / 256;
+  constexpr int STAGE_FLOATS = (BM + BN) * BK;
+
+  const clipfs_gemm_args& g = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = blockIdx.x;
+  const int m0 = (bid / p.n_blocks_n) * BM;
+  const int n0 = (bid % p.n_blocks_n) * BN;
+  const int M = g.M, N = g.N, K = g.K;
+
+  // ---- staging addresses -------------------------------------------------------------------
+  const float* a_src[A_CHUNKS];
+  int a_lds[A_CHUNKS];
+  const int kc = tid & 7;  // chunk (4 floats) inside the 32-wide K-step, same for every chunk id
+#pragma unroll
+  for (int i = 0; i < A_CHUNKS; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    const int m = min(m0 + row, M - 1);
+    if (g.a_mode == 0) {
+      a_src[i] = g.A + (size_t)m * g.lda;
+    } else {
+      const int b = m / p.patches, pp = m - b * p.patches;
+      const int py = pp / p.grid_g, px = pp - py * p.grid_g;
+      a_src[i] = g.A + ((size_t)b * 3 * g.img_res + (size_t)py * g.patch) * g.img_res + (size_t)px * g.patch;
+    }
+    a_lds[i] = row * BK + ((kc ^ ((row >> 1) & 7)) << 2);
+  }
+  const float* b_src[B_CHUNKS];
+  int b_lds[B_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < B_CHUNKS; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    const int n = min(n0 + row, N - 1);
+    b_src[i] = g.B + (size_t)n * g.ldb;
+    b_lds[i] = BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2);
+  }
+
+  float4 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
+  auto load_global = [&](int k0) {
+    const int k = k0 + kc * 4;
+    const bool k_ok = k < K;  // K % 4 == 0 is checked on the host
+    if (g.a_mode == 0) {
+#pragma unroll
+      for (int i = 0; i < A_CHUNKS; ++i)
+        a_reg[i] = k_ok ? *reinterpret_cast<const float4*>(a_src[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      // k -> (channel, ky, kx); a 4-chunk never crosses a patch row when patch % 4 == 0
+      const int pp2 = g.patch * g.patch;
+      const int c = k / pp2, rem = k - c * pp2;
+      const int ky = rem / g.patch, kx = rem - ky * g.patch;
+      const size_t off = ((size_t)c * g.img_res + ky) * g.img_res + kx;
+#pragma unroll
+      for (int i = 0; i < A_CHUNKS; ++i) {
+        if (!k_ok) {
+          a_reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if ((g.patch & 3) == 0) {
+          a_reg[i] = *reinterpret_cast<const float4*>(a_src[i] + off);
+        } else {
+          float t[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kk = k + e;
+            const int c2 = kk / pp2, r2 = kk - c2 * pp2;
+            const int ky2 = r2 / g.patch, kx2 = r2 - ky2 * g.patch;
+            t[e] = kk < K ? a_src[i][((size_t)c2 * g.img_res + ky2) * g.img_res + kx2] : 0.f;
+          }
+          a_reg[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i)
+      b_reg[i] = k_ok ? *reinterpret_cast<const float4*>(b_src[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_lds = [&](int stage) {
+    float* s = smem + stage * STAGE_FLOATS;
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) *reinterpret_cast<float4*>(s + a_lds[i]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) *reinterpret_cast<float4*>(s + b_lds[i]) = b_reg[i];
+  };
+
+  // ---- fragment read addresses -----------------------------------------------------------------
+  const int fr = lane & 31, fh = lane >> 5;
+  const int swz = (fr >> 1) & 7;  // (row >> 1) & 7 : tile bases are multiples of 32
+  int a_frag[TM], b_frag[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) a_frag[t] = (wm * (BM / 2) + t * 32 + fr) * BK;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) b_frag[t] = BM * BK + (wn * (BN / 2) + t * 32 + fr) * BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + BK - 1) / BK;
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_global((kt + 1) * BK);
+    const float* s = smem + (kt & 1) * STAGE_FLOATS;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = (((2 * q + fh) ^ swz) << 2);
+      float4 av[TM], bv[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) av[t] = *reinterpret_cast<const float4*>(s + a_frag[t] + ch);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bv[t] = *reinterpret_cast<const float4*>(s + b_frag[t] + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float ae = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float be = e == 0 ? bv[j].x : e == 1 ? bv[j].y : e == 2 ? bv[j].z : bv[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (more) store_lds((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+    const bool n_ok = n < N;
+    const int nc = n_ok ? n : N - 1;
+    const float bias = g.bias ? g.bias[nc] : 0.f;
+    const float* lb = nullptr;
+    int lseg = 0;
+    if (g.lora_t) {
+      lseg = nc / g.lora_seg_width;
+      lb = g.lora_b + (size_t)nc * g.lora_r;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m >= M || !n_ok) continue;
+        float v = g.alpha * acc[i][j][r] + bias;
+        if (lb) {
+          const float* t = g.lora_t + (size_t)m * (g.lora_nseg * g.lora_r) + lseg * g.lora_r;
+          float d = 0.f;
+          for (int jj = 0; jj < g.lora_r; ++jj) d = fmaf(t[jj], lb[jj], d);
+          v = fmaf(g.lora_scale, d, v);
+        }
+        size_t orow = (size_t)m;
+        size_t rrow = (size_t)m;
+        if (g.a_mode == 1) {
+          const int b = m / p.patches, pp = m - b * p.patches;
+          orow = (size_t)b * g.out_tokens + 1 + pp;
+          rrow = (size_t)(1 + pp);
+        }
+        if (g.act == 1) {
+          if (g.aux_out) g.aux_out[orow * g.ldc + n] = v;
+          v = quick_gelu(v);
+        } else if (g.act == 2) {
+          v *= quick_gelu_grad(g.aux_in[orow * g.ldc + n]);
+        }
+        if (g.residual) v += g.residual[rrow * g.ldres + n];
+        g.C[orow * g.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static int launch(const GemmParams& p, hipStream_t stream) {
+  const int mb = (p.a.M + BM - 1) / BM;
+  const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
+  return launch_status();
+}
+
+}  // namespace clipfs
+
+using namespace clipfs;
+
+extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
+  CLIPFS_REQUIRE(args != nullptr, "gemm: null args");
+  const clipfs_gemm_args& a = *args;
+  CLIPFS_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
+  CLIPFS_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad dims %d %d %d", a.M, a.N, a.K);
+  CLIPFS_REQUIRE((a.K & 3) == 0 && (a.ldb & 3) == 0 && aligned16(a.B), "gemm: K and ldb must be multiples of 4, B 16-byte aligned");
+  CLIPFS_REQUIRE(a.ldb >= a.K && a.ldc >= a.N, "gemm: leading dimension too small");
+  CLIPFS_REQUIRE(a.act >= 0 && a.act <= 2, "gemm: bad act %d", a.act);
+  CLIPFS_REQUIRE(a.act != 2 || a.aux_in, "gemm: act 2 needs aux_in");
+  CLIPFS_REQUIRE(!a.residual || a.ldres >= a.N, "gemm: ldres too small");
+  GemmParams p;
+  p.a = a;
+  p.patches = 0;
+  p.grid_g = 0;
+  if (a.a_mode == 0) {
+    CLIPFS_REQUIRE((a.lda & 3) == 0 && a.lda >= a.K && aligned16(a.A), "gemm: lda must be a multiple of 4 and >= K, A 16-byte aligned");
+  } else {
+    CLIPFS_REQUIRE(a.a_mode == 1, "gemm: bad a_mode %d", a.a_mode);
+    CLIPFS_REQUIRE(a.patch > 0 && a.img_res % a.patch == 0, "gemm: image %d not divisible by patch %d", a.img_res, a.patch);
+    p.grid_g = a.img_res / a.patch;
+    p.patches = p.grid_g * p.grid_g;
+    CLIPFS_REQUIRE(a.K == 3 * a.patch * a.patch, "gemm: patch mode needs K == 3*patch^2");
+    CLIPFS_REQUIRE(a.M % p.patches == 0 && a.out_tokens >= p.patches + 1, "gemm: patch mode shape mismatch");
+    CLIPFS_REQUIRE((a.patch & 3) != 0 || ((a.img_res & 3) == 0 && aligned16(a.A)), "gemm: image rows must be 16-byte aligned");
+  }
+  if (a.lora_t) {
+    CLIPFS_REQUIRE(a.lora_b && a.lora_r > 0 && a.lora_nseg > 0 && a.lora_seg_width > 0, "gemm: bad lora args");
+    CLIPFS_REQUIRE(a.lora_seg_width % 32 == 0 && a.lora_seg_width * a.lora_nseg >= a.N, "gemm: lora segment width must be a multiple of 32 and cover N");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // 64x128 tiles keep the tile count a large multiple of the CU count at the path's shapes
+  // (M = 12800: 200 x N/128 tiles), 128x128 is used when there are plenty of tiles anyway.
+  p.n_blocks_n = (a.N + 127) / 128;
+  return launch<64, 128>(p, s);
+}

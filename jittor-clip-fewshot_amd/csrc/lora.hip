@@ -1,0 +1,329 @@
+// LoRA adapter kernels.  The reference materialises B@A ([d,d]) and runs a second full d x d GEMM
+// per adapted projection (lora_train_vlp.py:218-221,302: +26 % FLOPs); here the rank-r form is kept:
+//   down : t = drop(x) A^T           [rows, nseg*r]   (this file, HBM-bound: one read of x)
+//   up   : y += scale * t B^T        (fused into the GEMM epilogue, gemm.hip)
+// and the backward is three skinny products that each read their big operand exactly once.
+#include "common.h"
+
+namespace clipfs {
+
+constexpr int LORA_MAX_CHUNKS = 8;  // width <= 2048
+constexpr int LORA_MAX_OUT = 64;    // nseg * r
+
+// one wave per row
+__global__ __launch_bounds__(256) void lora_down_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                                                        float* __restrict__ t, int rows, int width, int r, int nseg,
+                                                        unsigned seg_mask, float p, uint64_t seed,
+                                                        uint32_t stream_base) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = width >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * width);
+  float4 v[LORA_MAX_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < LORA_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) v[i] = xr[c];
+  }
+  const bool drop = p > 0.f && seed != 0;
+  const uint32_t thr = dropout_threshold(p);
+  const float inv_keep = 1.f / (1.f - p);
+  float* trow = t + (size_t)row * (nseg * r);
+  for (int s = 0; s < nseg; ++s) {
+    if (!((seg_mask >> s) & 1u)) {
+      if (lane < r) trow[s * r + lane] = 0.f;
+      continue;
+    }
+    float4 xs[LORA_MAX_CHUNKS];
+#pragma unroll
+    for (int i = 0; i < LORA_MAX_CHUNKS; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        xs[i] = v[i];
+        if (drop) {
+          const float4 m = dropout_scale4(seed, stream_base + s, (uint32_t)row, (uint32_t)c, thr, inv_keep);
+          xs[i].x *= m.x;
+          xs[i].y *= m.y;
+          xs[i].z *= m.z;
+          xs[i].w *= m.w;
+        }
+      }
+    }
+    for (int j = 0; j < r; ++j) {
+      const float4* ar = reinterpret_cast<const float4*>(A + (size_t)(s * r + j) * width);
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < LORA_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          const float4 a = ar[c];
+          acc += (xs[i].x * a.x + xs[i].y * a.y) + (xs[i].z * a.z + xs[i].w * a.w);
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) trow[s * r + j] = acc;
+    }
+  }
+}
+
+// dt[m, s*r+j] = scale * sum_n dy[m, s*segw+n] * B[s*segw+n, j]     one wave per row
+__global__ __launch_bounds__(256) void lora_dt_kernel(const float* __restrict__ dy, const float* __restrict__ B,
+                                                      float* __restrict__ dt, int rows, int segw, int r, int nseg,
+                                                      unsigned seg_mask, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* dr = dy + (size_t)row * nseg * segw;
+  float* out = dt + (size_t)row * nseg * r;
+  for (int s = 0; s < nseg; ++s) {
+    if (!((seg_mask >> s) & 1u)) {
+      if (lane < r) out[s * r + lane] = 0.f;
+      continue;
+    }
+    for (int j0 = 0; j0 < r; j0 += 4) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int n = lane; n < segw; n += 64) {
+        const float g = dr[s * segw + n];
+        const float* b = B + (size_t)(s * segw + n) * r + j0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (j0 + jj < r) acc[jj] = fmaf(g, b[jj], acc[jj]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float v = wave_sum(acc[jj]);
+        if (lane == 0 && j0 + jj < r) out[s * r + j0 + jj] = scale * v;
+      }
+    }
+  }
+}
+
+// Column-parallel tall reduction:  part[slice][c][j] = sum_{m in slice} X[m, c] * T[m, toff(c) + j]
+// thread = one column c (coalesced across lanes), T row values are wave-uniform broadcasts.
+// Used for dB (X = dy, T = t) -- deterministic two stage sum (no float atomics).
+template <int R>
+__global__ __launch_bounds__(256) void lora_db_partial_kernel(const float* __restrict__ dy, const float* __restrict__ t,
+                                                              float* __restrict__ part, int rows, int cols, int segw,
+                                                              int nseg, int rows_per_slice) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int slice = blockIdx.y;
+  if (c >= cols) return;
+  const int s = c / segw;
+  const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
+  float acc[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) acc[j] = 0.f;
+  const int tw = nseg * R;
+  for (int m = m0; m < m1; ++m) {
+    const float g = dy[(size_t)m * cols + c];
+    const float* tr = t + (size_t)m * tw + s * R;
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[j] = fmaf(g, tr[j], acc[j]);
+  }
+  float* o = part + ((size_t)slice * cols + c) * R;
+#pragma unroll
+  for (int j = 0; j < R; ++j) o[j] = acc[j];
+}
+
+// dA partials: thread = 4 consecutive columns k of x; acc[s][j] over the slice's rows, dropout
+// multipliers regenerated from the Philox stream (never stored).
+template <int R, int NSEG>
+__global__ __launch_bounds__(256) void lora_da_partial_kernel(const float* __restrict__ x, const float* __restrict__ dt,
+                                                              float* __restrict__ part, int rows, int width,
+                                                              unsigned seg_mask, float p, uint64_t seed,
+                                                              uint32_t stream_base, int rows_per_slice) {
+  const int c4 = blockIdx.x * 256 + threadIdx.x;  // chunk of 4 columns
+  const int slice = blockIdx.y;
+  if (c4 * 4 >= width) return;
+  const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
+  const bool drop = p > 0.f && seed != 0;
+  const uint32_t thr = dropout_threshold(p);
+  const float inv_keep = 1.f / (1.f - p);
+  float4 acc[NSEG][R];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[s][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int m = m0; m < m1; ++m) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * width + 4 * c4);
+    const float* dr = dt + (size_t)m * (NSEG * R);
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+      if (!((seg_mask >> s) & 1u)) continue;
+      float4 xs = xv;
+      if (drop) {
+        const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)m, (uint32_t)c4, thr, inv_keep);
+        xs.x *= mk.x;
+        xs.y *= mk.y;
+        xs.z *= mk.z;
+        xs.w *= mk.w;
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const float g = dr[s * R + j];
+        acc[s][j].x = fmaf(g, xs.x, acc[s][j].x);
+        acc[s][j].y = fmaf(g, xs.y, acc[s][j].y);
+        acc[s][j].z = fmaf(g, xs.z, acc[s][j].z);
+        acc[s][j].w = fmaf(g, xs.w, acc[s][j].w);
+      }
+    }
+  }
+  // part layout [slice][s*R + j][width]
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      *reinterpret_cast<float4*>(part + ((size_t)slice * (NSEG * R) + s * R + j) * width + 4 * c4) = acc[s][j];
+}
+
+// out[i] += sum_slice part[slice][i]      (fixed order => bitwise reproducible)
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            size_t n, int slices, float scale) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < slices; ++s) acc += part[(size_t)s * n + i];
+  out[i] += scale * acc;
+}
+
+// dx[m,k] += sum_{s,j} dt[m, s*r+j] * A[s*r+j, k] * dropscale_s(m,k)       one wave per row
+__global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ dt, const float* __restrict__ A,
+                                                      float* __restrict__ dx, int rows, int width, int r, int nseg,
+                                                      unsigned seg_mask, float p, uint64_t seed,
+                                                      uint32_t stream_base) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = width >> 2;
+  const bool drop = p > 0.f && seed != 0;
+  const uint32_t thr = dropout_threshold(p);
+  const float inv_keep = 1.f / (1.f - p);
+  const float* dr = dt + (size_t)row * nseg * r;
+  float4* xr = reinterpret_cast<float4*>(dx + (size_t)row * width);
+  for (int c = lane; c < nch; c += 64) {
+    float4 tot = xr[c];
+    for (int s = 0; s < nseg; ++s) {
+      if (!((seg_mask >> s) & 1u)) continue;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < r; ++j) {
+        const float g = dr[s * r + j];
+        const float4 av = *reinterpret_cast<const float4*>(A + (size_t)(s * r + j) * width + 4 * c);
+        a.x = fmaf(g, av.x, a.x);
+        a.y = fmaf(g, av.y, a.y);
+        a.z = fmaf(g, av.z, a.z);
+        a.w = fmaf(g, av.w, a.w);
+      }
+      if (drop) {
+        const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)row, (uint32_t)c, thr, inv_keep);
+        a.x *= mk.x;
+        a.y *= mk.y;
+        a.z *= mk.z;
+        a.w *= mk.w;
+      }
+      tot.x += a.x;
+      tot.y += a.y;
+      tot.z += a.z;
+      tot.w += a.w;
+    }
+    xr[c] = tot;
+  }
+}
+
+constexpr int LORA_SLICE_ROWS = 256;
+
+}  // namespace clipfs
+
+using namespace clipfs;
+
+extern "C" int clipfs_lora_down(const float* x, const float* A, float* t, int rows, int width, int r, int nseg,
+                                unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, void* stream) {
+  CLIPFS_REQUIRE(x && A && t, "lora_down: null pointer");
+  CLIPFS_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0 && width <= 256 * LORA_MAX_CHUNKS, "lora_down: width %d unsupported", width);
+  CLIPFS_REQUIRE(r > 0 && r <= 64 && nseg > 0 && nseg <= 4 && nseg * r <= LORA_MAX_OUT, "lora_down: r %d nseg %d unsupported", r, nseg);
+  CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_down: dropout p %f out of range", (double)p);
+  CLIPFS_REQUIRE(aligned16(x) && aligned16(A), "lora_down: misaligned pointer");
+  hipLaunchKernelGGL(lora_down_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, A, t, rows, width, r,
+                     nseg, seg_mask, p, seed, stream_base);
+  return launch_status();
+}
+
+extern "C" size_t clipfs_lora_bwd_work_floats(int rows, int width, int r, int nseg) {
+  const size_t slices = (size_t)(rows + LORA_SLICE_ROWS - 1) / LORA_SLICE_ROWS;
+  // dB partials: slices * (nseg*segw) * r with segw <= 4*width (MLP never adapted; q/k/v/o segw == width)
+  // dA partials: slices * nseg * r * width
+  return slices * (size_t)nseg * r * width * 2 + 64;
+}
+
+template <int R>
+static int lora_bwd_r(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
+                      float* dA, float* dB, float* dx, int rows, int width, int segw, int nseg, unsigned seg_mask,
+                      float scale, float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st) {
+  const int slices = (rows + LORA_SLICE_ROWS - 1) / LORA_SLICE_ROWS;
+  const int cols = nseg * segw;
+  hipLaunchKernelGGL(lora_dt_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, B, dt, rows, segw, R, nseg, seg_mask,
+                     scale);
+  CLIPFS_CHECK(launch_status());
+  // dB
+  float* part_b = work;
+  hipLaunchKernelGGL((lora_db_partial_kernel<R>), dim3((cols + 255) / 256, slices), dim3(256), 0, st, dy, t, part_b,
+                     rows, cols, segw, nseg, LORA_SLICE_ROWS);
+  CLIPFS_CHECK(launch_status());
+  const size_t nb = (size_t)cols * R;
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, part_b, dB, nb, slices,
+                     scale);
+  CLIPFS_CHECK(launch_status());
+  // dA
+  float* part_a = work + (size_t)slices * nb;
+  const dim3 ga((width / 4 + 255) / 256, slices);
+  switch (nseg) {
+    case 1:
+      hipLaunchKernelGGL((lora_da_partial_kernel<R, 1>), ga, dim3(256), 0, st, x, dt, part_a, rows, width, seg_mask, p,
+                         seed, stream_base, LORA_SLICE_ROWS);
+      break;
+    case 3:
+      hipLaunchKernelGGL((lora_da_partial_kernel<R, 3>), ga, dim3(256), 0, st, x, dt, part_a, rows, width, seg_mask, p,
+                         seed, stream_base, LORA_SLICE_ROWS);
+      break;
+    default:
+      set_error("lora_bwd: nseg %d unsupported (1 or 3)", nseg);
+      return CLIPFS_EINVAL;
+  }
+  CLIPFS_CHECK(launch_status());
+  const size_t na = (size_t)nseg * R * width;
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, part_a, dA, na, slices,
+                     1.0f);
+  CLIPFS_CHECK(launch_status());
+  if (dx) {
+    hipLaunchKernelGGL(lora_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dt, A, dx, rows, width, R, nseg, seg_mask,
+                       p, seed, stream_base);
+    CLIPFS_CHECK(launch_status());
+  }
+  return CLIPFS_OK;
+}
+
+extern "C" int clipfs_lora_bwd(const float* dy, const float* x, const float* t, const float* A, const float* B,
+                               float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
+                               int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
+                               float* work, void* stream) {
+  CLIPFS_REQUIRE(dy && x && t && A && B && dt && dA && dB && work, "lora_bwd: null pointer");
+  CLIPFS_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0 && segw == width, "lora_bwd: width %d segw %d unsupported (segw must equal width)", width, segw);
+  CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_bwd: dropout p out of range");
+  CLIPFS_REQUIRE(aligned16(x) && aligned16(A) && aligned16(work) && (!dx || aligned16(dx)), "lora_bwd: misaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+#define CLIPFS_LORA_CASE(RR)                                                                                       \
+  case RR:                                                                                                         \
+    return lora_bwd_r<RR>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, nseg, seg_mask, scale, p, seed,       \
+                          stream_base, work, st)
+  switch (r) {
+    CLIPFS_LORA_CASE(1);
+    CLIPFS_LORA_CASE(2);
+    CLIPFS_LORA_CASE(4);
+    CLIPFS_LORA_CASE(8);
+    CLIPFS_LORA_CASE(16);
+    default:
+      set_error("lora_bwd: rank %d unsupported (1, 2, 4, 8, 16)", r);
+      return CLIPFS_EINVAL;
+  }
+#undef CLIPFS_LORA_CASE
+}

@@ -1,0 +1,226 @@
+// LayerNorm forward / backward and row L2-normalisation: HBM-bound, one wave64 per row,
+// 16-byte loads, statistics by cross-lane shuffles (no LDS).  Algorithmic bytes per row:
+// fwd 2*width*4 (+8 for mean/rstd), bwd 3..4*width*4.
+#include "common.h"
+
+namespace clipfs {
+
+constexpr int LN_MAX_CHUNKS = 8;  // 8 * 64 lanes * 4 floats = width <= 2048
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int rows, int width, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = width >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+  float4 v[LN_MAX_CHUNKS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      v[i] = xr[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)width;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)width + eps);
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * width);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 g = g4[c], b = b4[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      yr[c] = o;
+    }
+  }
+  if (mean_out && lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            int ldx, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in,
+                                                            const float* dres, float* dx,  // may alias (in-place residual add)
+                                                            int lddx, int rows, int width) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = width >> 2;
+  const float mean = mean_in[row], rstd = rstd_in[row];
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+  const float4* dyr = reinterpret_cast<const float4*>(dy + (size_t)row * width);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  float4 xh[LN_MAX_CHUNKS], gd[LN_MAX_CHUNKS];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 xv = xr[c], d = dyr[c], g = g4[c];
+      xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+      s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+    }
+  }
+  const float c1 = wave_sum(s1) / (float)width;
+  const float c2 = wave_sum(s2) / (float)width;
+  float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * lddx);
+  const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * lddx) : nullptr;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float4 o;
+      o.x = rstd * (gd[i].x - c1 - xh[i].x * c2);
+      o.y = rstd * (gd[i].y - c1 - xh[i].y * c2);
+      o.z = rstd * (gd[i].z - c1 - xh[i].z * c2);
+      o.w = rstd * (gd[i].w - c1 - xh[i].w * c2);
+      if (rr) {
+        const float4 r = rr[c];
+        o.x += r.x;
+        o.y += r.y;
+        o.z += r.z;
+        o.w += r.w;
+      }
+      dxr[c] = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ inv_out, int rows, int width) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = width >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * width);
+  float4 v[LN_MAX_CHUNKS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      v[i] = xr[c];
+      s += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+  }
+  const float inv = 1.f / sqrtf(wave_sum(s));
+  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * width);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) yr[c] = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+  }
+  if (inv_out && lane == 0) inv_out[row] = inv;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ inv_in, float* __restrict__ dx,
+                                                         int rows, int width) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = width >> 2;
+  const float4* yr = reinterpret_cast<const float4*>(y + (size_t)row * width);
+  const float4* dr = reinterpret_cast<const float4*>(dy + (size_t)row * width);
+  float4 yv[LN_MAX_CHUNKS], dv[LN_MAX_CHUNKS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      yv[i] = yr[c];
+      dv[i] = dr[c];
+      s += (yv[i].x * dv[i].x + yv[i].y * dv[i].y) + (yv[i].z * dv[i].z + yv[i].w * dv[i].w);
+    }
+  }
+  const float dot = wave_sum(s);
+  const float inv = inv_in[row];
+  float4* xr = reinterpret_cast<float4*>(dx + (size_t)row * width);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch)
+      xr[c] = make_float4(inv * (dv[i].x - yv[i].x * dot), inv * (dv[i].y - yv[i].y * dot),
+                          inv * (dv[i].z - yv[i].z * dot), inv * (dv[i].w - yv[i].w * dot));
+  }
+}
+
+static int check_rows(const char* what, int rows, int width) {
+  CLIPFS_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0 && width <= 256 * LN_MAX_CHUNKS,
+                 "%s: rows %d width %d unsupported (width must be a multiple of 4, <= %d)", what, rows, width,
+                 256 * LN_MAX_CHUNKS);
+  return CLIPFS_OK;
+}
+
+}  // namespace clipfs
+
+using namespace clipfs;
+
+extern "C" int clipfs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y,
+                                    float* mean, float* rstd, int rows, int width, float eps, void* stream) {
+  CLIPFS_CHECK(check_rows("layernorm_fwd", rows, width));
+  CLIPFS_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  CLIPFS_REQUIRE((mean == nullptr) == (rstd == nullptr), "layernorm_fwd: mean and rstd must both be given or both NULL");
+  CLIPFS_REQUIRE(ldx >= width && (ldx & 3) == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta),
+                 "layernorm_fwd: alignment");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                     y, mean, rstd, rows, width, eps);
+  return launch_status();
+}
+
+extern "C" int clipfs_layernorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* mean,
+                                    const float* rstd, const float* dres, float* dx, int lddx, int rows, int width,
+                                    void* stream) {
+  CLIPFS_CHECK(check_rows("layernorm_bwd", rows, width));
+  CLIPFS_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  CLIPFS_REQUIRE(ldx >= width && (ldx & 3) == 0 && lddx >= width && (lddx & 3) == 0 && aligned16(x) && aligned16(dy) &&
+                     aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)),
+                 "layernorm_bwd: alignment");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, ldx, gamma,
+                     mean, rstd, dres, dx, lddx, rows, width);
+  return launch_status();
+}
+
+extern "C" int clipfs_l2norm_fwd(const float* x, float* y, float* inv_norm, int rows, int width, void* stream) {
+  CLIPFS_CHECK(check_rows("l2norm_fwd", rows, width));
+  CLIPFS_REQUIRE(x && y && aligned16(x) && aligned16(y), "l2norm_fwd: null or misaligned pointer");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, rows,
+                     width);
+  return launch_status();
+}
+
+extern "C" int clipfs_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int rows, int width,
+                                 void* stream) {
+  CLIPFS_CHECK(check_rows("l2norm_bwd", rows, width));
+  CLIPFS_REQUIRE(dy && y && inv_norm && dx && aligned16(dy) && aligned16(y) && aligned16(dx),
+                 "l2norm_bwd: null or misaligned pointer");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx,
+                     rows, width);
+  return launch_status();
+}

@@ -1,0 +1,192 @@
+// Host-side sequencing of one transformer tower (forward and backward): the C++ runtime that replaces
+// Jittor's graph executor for Transformer / ResidualAttentionBlock (jclip/model.py:42-77),
+// PlainMultiheadAttentionLoRA (lora_train_vlp.py:431-506) and their autograd.  One call enqueues
+// every kernel of the pass on the caller's stream; no allocation, no synchronisation.
+//
+// Residual stream without copies: block l reads x_in[l], the out-projection epilogue writes
+// x_mid[l] = x_in[l] + attn, the c_proj epilogue writes x_in[l+1] = x_mid[l] + mlp, so the tensors the
+// backward needs are exactly the ones the forward had to produce anyway.
+#include "common.h"
+
+namespace clipfs {
+
+static inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+struct SavedLayout {
+  size_t x_in, stat1, h1, t_qkv, qkv, att, t_o, x_mid, stat2, u, total;
+};
+
+static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
+  const size_t d = t->width, r = t->lora_r > 0 ? t->lora_r : 0;
+  SavedLayout L;
+  size_t o = 0;
+  L.x_in = o;  o += al4(M * d);
+  L.stat1 = o; o += al4(2 * M);
+  L.h1 = o;    o += al4(M * d);
+  L.t_qkv = o; o += al4(M * 3 * r);
+  L.qkv = o;   o += al4(M * 3 * d);
+  L.att = o;   o += al4(M * d);
+  L.t_o = o;   o += al4(M * r);
+  L.x_mid = o; o += al4(M * d);
+  L.stat2 = o; o += al4(2 * M);
+  L.u = o;     o += al4(M * 4 * d);
+  L.total = o;
+  return L;
+}
+
+struct ScratchLayout {
+  size_t h, big, b3, b1, dt, work, total;
+};
+
+static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
+  const size_t d = t->width, r = t->lora_r > 0 ? t->lora_r : 0;
+  ScratchLayout S;
+  size_t o = 0;
+  S.h = o;    o += al4(M * d);
+  S.big = o;  o += al4(M * 4 * d);
+  S.b3 = o;   o += al4(M * 3 * d);
+  S.b1 = o;   o += al4(M * d);
+  S.dt = o;   o += al4(M * 4 * r);
+  S.work = o; o += r ? al4(clipfs_lora_bwd_work_floats((int)M, (int)d, (int)r, 3)) : 0;
+  S.total = o;
+  return S;
+}
+
+static int check_tower(const clipfs_tower* t, int batch) {
+  CLIPFS_REQUIRE(t && t->blocks, "tower: null descriptor");
+  CLIPFS_REQUIRE(batch > 0 && t->layers > 0 && t->seq > 0 && t->heads > 0 && t->width == t->heads * 64,
+                 "tower: width %d must be heads %d * 64", t->width, t->heads);
+  CLIPFS_REQUIRE(t->lora_r >= 0 && t->lora_r <= 16, "tower: lora rank %d unsupported", t->lora_r);
+  return CLIPFS_OK;
+}
+
+static int gemm(const float* A, const float* B, float* C, int M, int N, int K, const float* bias, const float* res,
+                int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r, int nseg,
+                int segw, float lscale, hipStream_t st) {
+  clipfs_gemm_args a = {};
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
+  a.lda = K; a.ldb = K; a.ldc = N; a.alpha = 1.f;
+  a.bias = bias; a.residual = res; a.ldres = N;
+  a.act = act; a.aux_out = aux_out; a.aux_in = aux_in;
+  a.lora_t = lt; a.lora_b = lb; a.lora_r = r; a.lora_nseg = nseg; a.lora_seg_width = segw; a.lora_scale = lscale;
+  return clipfs_gemm_nt(&a, st);
+}
+
+}  // namespace clipfs
+
+using namespace clipfs;
+
+extern "C" size_t clipfs_tower_saved_floats(const clipfs_tower* t, int batch) {
+  if (!t || batch <= 0) return 0;
+  return saved_layout(t, (size_t)batch * t->seq).total * (size_t)t->layers;
+}
+
+extern "C" size_t clipfs_tower_scratch_floats(const clipfs_tower* t, int batch) {
+  if (!t || batch <= 0) return 0;
+  return scratch_layout(t, (size_t)batch * t->seq).total;
+}
+
+extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, float* scratch, void* stream) {
+  CLIPFS_CHECK(check_tower(t, batch));
+  CLIPFS_REQUIRE(x && scratch, "tower_fwd: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = batch * t->seq, d = t->width, r = t->lora_r;
+  const SavedLayout SL = saved_layout(t, (size_t)M);
+  const ScratchLayout SC = scratch_layout(t, (size_t)M);
+  const bool train = saved != nullptr;
+  const uint64_t seed = train ? t->dropout_seed : 0;  // dropout only when training (is_training(), :298)
+  if (train) {
+    hipError_t e = hipMemcpyAsync(saved + SL.x_in, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    CLIPFS_REQUIRE(e == hipSuccess, "tower_fwd: memcpy failed: %s", hipGetErrorString(e));
+  }
+  for (int l = 0; l < t->layers; ++l) {
+    const clipfs_block& b = t->blocks[l];
+    float* sv = train ? saved + (size_t)l * SL.total : nullptr;
+    const float* x_in = train ? sv + SL.x_in : x;
+    float* h1 = train ? sv + SL.h1 : scratch + SC.h;
+    float* qkv = train ? sv + SL.qkv : scratch + SC.b3;
+    float* att = train ? sv + SL.att : scratch + SC.b1;
+    float* x_mid = train ? sv + SL.x_mid : x;
+    float* t_qkv = train ? sv + SL.t_qkv : scratch + SC.dt;
+    float* t_o = train ? sv + SL.t_o : scratch + SC.dt + al4((size_t)M * 3 * r);
+    float* x_next = train ? (l + 1 < t->layers ? saved + (size_t)(l + 1) * SL.total + SL.x_in : x) : x;
+    const unsigned qkv_mask = b.lora_a_qkv ? (b.lora_mask & 7u) : 0u;
+    const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
+    const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
+
+    CLIPFS_CHECK(clipfs_layernorm_fwd(x_in, d, b.ln1_g, b.ln1_b, h1, train ? sv + SL.stat1 : nullptr,
+                                      train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
+    if (qkv_mask)
+      CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, st));
+    CLIPFS_CHECK(gemm(h1, b.w_qkv, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
+                      b.lora_b_qkv, r, 3, d, t->lora_scale, st));
+    CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, batch, t->seq, t->heads, t->causal, st));
+    if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, st));
+    CLIPFS_CHECK(gemm(att, b.w_o, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
+                      1, d, t->lora_scale, st));
+    float* h2 = scratch + SC.h;
+    CLIPFS_CHECK(clipfs_layernorm_fwd(x_mid, d, b.ln2_g, b.ln2_b, h2, train ? sv + SL.stat2 : nullptr,
+                                      train ? sv + SL.stat2 + M : nullptr, M, d, 1e-5f, st));
+    float* gbuf = scratch + SC.big;
+    CLIPFS_CHECK(gemm(h2, b.w_fc, gbuf, M, 4 * d, d, b.b_fc, nullptr, 1, train ? sv + SL.u : nullptr, nullptr, nullptr,
+                      nullptr, 0, 0, 0, 0.f, st));
+    CLIPFS_CHECK(gemm(gbuf, b.w_pr, x_next, M, d, 4 * d, b.b_pr, x_mid, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+                      0.f, st));
+  }
+  return CLIPFS_OK;
+}
+
+extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, const float* saved, float* scratch,
+                                int stop_at_input, void* stream) {
+  CLIPFS_CHECK(check_tower(t, batch));
+  CLIPFS_REQUIRE(dx && saved && scratch, "tower_bwd: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = batch * t->seq, d = t->width, r = t->lora_r;
+  const SavedLayout SL = saved_layout(t, (size_t)M);
+  const ScratchLayout SC = scratch_layout(t, (size_t)M);
+  const uint64_t seed = t->dropout_seed;
+  for (int l = t->layers - 1; l >= 0; --l) {
+    const clipfs_block& b = t->blocks[l];
+    const float* sv = saved + (size_t)l * SL.total;
+    CLIPFS_REQUIRE(b.w_pr_t && b.w_fc_t && b.w_o_t && b.w_qkv_t, "tower_bwd: block %d lacks transposed weights", l);
+    const unsigned qkv_mask = b.lora_a_qkv ? (b.lora_mask & 7u) : 0u;
+    const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
+    const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
+    float* du = scratch + SC.big;
+    float* dh = scratch + SC.h;
+    float* datt = scratch + SC.b1;
+    float* dqkv = scratch + SC.b3;
+    float* dt = scratch + SC.dt;
+    float* work = scratch + SC.work;
+    // MLP: du = (dx Wpr) * gelu'(u) ; dh2 = du Wfc ; dx += LN2'(dh2)
+    CLIPFS_CHECK(gemm(dx, b.w_pr_t, du, M, 4 * d, d, nullptr, nullptr, 2, nullptr, sv + SL.u, nullptr, nullptr, 0, 0, 0,
+                      0.f, st));
+    CLIPFS_CHECK(gemm(du, b.w_fc_t, dh, M, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
+                      st));
+    CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, d, M, d,
+                                      st));
+    // attention output projection
+    CLIPFS_CHECK(gemm(dx, b.w_o_t, datt, M, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
+                      st));
+    if (lora_o) {
+      CLIPFS_REQUIRE(b.g_lora_a_o && b.g_lora_b_o, "tower_bwd: block %d o-LoRA gradient slots missing", l);
+      CLIPFS_CHECK(clipfs_lora_bwd(dx, sv + SL.att, sv + SL.t_o, b.lora_a_o, b.lora_b_o, dt, b.g_lora_a_o, b.g_lora_b_o,
+                                   datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, work, st));
+    }
+    CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, dqkv, batch, t->seq, t->heads, t->causal, st));
+    const bool need_dx = !(l == 0 && stop_at_input);
+    if (need_dx)
+      CLIPFS_CHECK(gemm(dqkv, b.w_qkv_t, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+                        0.f, st));
+    if (qkv_mask) {
+      CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);
+      CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
+                                   b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
+                                   t->lora_dropout, seed, ds, work, st));
+    }
+    if (need_dx)
+      CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_in, d, b.ln1_g, sv + SL.stat1, sv + SL.stat1 + M, dx, dx, d, M, d,
+                                        st));
+  }
+  return CLIPFS_OK;
+}

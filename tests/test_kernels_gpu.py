@@ -1,0 +1,324 @@
+"""Kernel-level parity: every HIP kernel (through the C ABI) against the CPU oracle / an fp64 torch
+restatement of the same op on the same seeded inputs.  Tolerances are absolute on O(1) data and are
+stated per test; GEMM-family kernels are exact-f32 MFMA fma chains, so errors are ~1e-6 * sqrt(K)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale)
+
+
+def _close(got, want, atol, what=""):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    err = (got - want).abs().max().item()
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.1e}"
+    return err
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(64, 128, 32), (200, 768, 768), (77 * 5, 192, 64), (130, 403, 512), (50, 64, 100),
+                                   (1000, 2304, 768)])
+def test_gemm_plain(dev, M, N, K):
+    from clipfs import ops
+    a, b = _rand(M, K, seed=1), _rand(N, K, seed=2)
+    out = ops.gemm_nt(a.float().to(dev), b.float().to(dev))
+    _close(out, a @ b.t(), 2e-5 * math.sqrt(K) * 4, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_asymmetric_layout(dev):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
+    from clipfs import ops
+    n = 128
+    a = torch.eye(n, dtype=torch.float32)
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 1000.0
+    out = ops.gemm_nt(a.to(dev), b.to(dev))
+    assert torch.equal(out.cpu(), b.t().contiguous())
+
+
+def test_gemm_epilogues(dev):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    M, N, K, r = 300, 384, 128, 4
+    a, w = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5)
+    bias, res = _rand(N, seed=5), _rand(M, N, seed=6)
+    t, lb = _rand(M, 3 * r, seed=7), _rand(N, r, seed=8)
+    D = lambda x: x.float().to(dev)
+    # bias + LoRA up-projection + residual
+    out = ops.gemm_nt(D(a), D(w), bias=D(bias), residual=D(res), lora_t=D(t), lora_b=D(lb), lora_seg_width=128,
+                      lora_scale=0.5)
+    want = a @ w.t() + bias + res
+    for s in range(3):
+        want[:, s * 128:(s + 1) * 128] += 0.5 * t[:, s * r:(s + 1) * r] @ lb[s * 128:(s + 1) * 128].t()
+    _close(out, want, 1e-4, "gemm bias+lora+residual")
+    # QuickGELU with saved pre-activation
+    u = torch.empty(M, N, device=dev)
+    out = ops.gemm_nt(D(a), D(w), bias=D(bias), act=1, aux_out=u)
+    pre = a @ w.t() + bias
+    _close(u, pre, 1e-4, "gemm pre-activation")
+    _close(out, O.quick_gelu(pre), 1e-4, "gemm quickgelu")
+    # backward of QuickGELU fused on a dgrad GEMM
+    up = _rand(M, N, seed=9).requires_grad_()
+    (O.quick_gelu(up)).sum().backward()
+    out = ops.gemm_nt(D(a), D(w), act=2, aux_in=D(up.detach()))
+    _close(out, (a @ w.t()) * up.grad, 1e-4, "gemm gelu-grad")
+    # alpha
+    out = ops.gemm_nt(D(a), D(w), alpha=100.0)
+    _close(out, 100.0 * (a @ w.t()), 2e-3, "gemm alpha")
+
+
+@pytest.mark.parametrize("B,R,ps,width", [(3, 64, 32, 128), (2, 224, 32, 768), (2, 28, 14, 64)])
+def test_patch_embed(dev, B, R, ps, width):
+    from clipfs import ops
+    img = _rand(B, 3, R, R, seed=1)
+    w = _rand(width, 3, ps, ps, seed=2, scale=(3 * ps * ps) ** -0.5)
+    P = (R // ps) ** 2
+    L = P + 1
+    pos = _rand(L, width, seed=3)
+    x = torch.zeros(B * L, width, device=dev)
+    ops.patch_embed(img.float().to(dev), w.float().to(dev), pos.float().to(dev), x, L)
+    conv = torch.nn.functional.conv2d(img, w, stride=ps).reshape(B, width, P).permute(0, 2, 1)
+    want = torch.zeros(B, L, width, dtype=torch.float64)
+    want[:, 1:] = conv + pos[1:]
+    _close(x.reshape(B, L, width), want, 1e-4, "patch embed")
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,width", [(7, 64), (1001, 768), (403, 512), (5, 1024)])
+def test_layernorm(dev, rows, width):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    x = (_rand(rows, width, seed=1) * 3 + 1).requires_grad_()
+    g, b = 1 + 0.1 * _rand(width, seed=2), _rand(width, seed=3)
+    D = lambda t: t.detach().float().to(dev)
+    y, mean, rstd = ops.layernorm_fwd(D(x), D(g), D(b), save_stats=True)
+    want = O.jt_layer_norm(x, g, b)
+    _close(y, want, 2e-5, "ln fwd")
+    dy, dres = _rand(rows, width, seed=4), _rand(rows, width, seed=5)
+    want.backward(dy)
+    dx = ops.layernorm_bwd(D(dy), D(x), D(g), mean, rstd, dres=D(dres))
+    _close(dx, x.grad + dres, 5e-5, "ln bwd")
+
+
+def test_layernorm_strided_rows(dev):
+    """ln_post reads the class-token rows of [B, L, d] in place (ldx = L*d)."""
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    B, L, d = 6, 5, 128
+    x = _rand(B, L, d, seed=1)
+    g, b = 1 + 0.1 * _rand(d, seed=2), _rand(d, seed=3)
+    D = lambda t: t.float().to(dev)
+    y = ops.layernorm_fwd(D(x), D(g), D(b), ldx=L * d, rows=B)
+    _close(y, O.jt_layer_norm(x[:, 0], g, b), 2e-5, "ln strided")
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,L,H,causal", [(3, 50, 2, False), (2, 54, 12, False), (3, 77, 8, True), (2, 16, 1, True),
+                                          (1, 5, 2, False), (2, 96, 2, True)])
+def test_attention(dev, B, L, H, causal):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    d = H * 64
+    qkv = _rand(B * L, 3 * d, seed=1).requires_grad_()
+    q, k, v = [qkv[:, i * d:(i + 1) * d].reshape(B, L, H, 64).permute(0, 2, 1, 3) for i in range(3)]
+    mask = O.build_causal_mask(L, torch.float64) if causal else None
+    o = O.sdpa(q, k, v, mask).permute(0, 2, 1, 3).reshape(B * L, d)
+    qd = qkv.detach().float().to(dev)
+    got = ops.attention_fwd(qd, B, L, H, causal)
+    _close(got, o, 2e-5, "attention fwd")
+    do = _rand(B * L, d, seed=2)
+    o.backward(do)
+    dq = ops.attention_bwd(qd, do.float().to(dev), B, L, H, causal)
+    _close(dq, qkv.grad, 5e-5, "attention bwd")
+
+
+# ------------------------------------------------------------------ LoRA
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_lora_down_and_bwd(dev, p):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    rows, width, r, nseg = 333, 128, 4, 3
+    seed, sb = 0x1234ABCD5, 7
+    x = _rand(rows, width, seed=1)
+    A = _rand(nseg * r, width, seed=2, scale=width ** -0.5).requires_grad_()
+    Bm = _rand(nseg * width, r, seed=3, scale=0.1).requires_grad_()
+    xs = x.clone().requires_grad_()
+    scale = 0.5
+    y = torch.zeros(rows, nseg * width, dtype=torch.float64)
+    ts = []
+    parts = []
+    for s in range(nseg):
+        m = torch.ones(rows, width, dtype=torch.float64)
+        if p > 0:
+            keep = O.dropout_keep_mask(seed, sb + s, rows, width, p)
+            m = torch.from_numpy(keep).double() / (1 - p)
+        t = (xs * m) @ A[s * r:(s + 1) * r].t()
+        ts.append(t)
+        parts.append(scale * t @ Bm[s * width:(s + 1) * width].t())
+    y = torch.cat(parts, dim=1)
+    D = lambda t: t.detach().float().to(dev)
+    t_gpu = ops.lora_down(D(x), D(A), r, nseg, p=p, seed=seed if p > 0 else 0, stream_base=sb)
+    _close(t_gpu, torch.cat(ts, dim=1), 2e-5, "lora down")
+    dy = _rand(rows, nseg * width, seed=4)
+    y.backward(dy)
+    dA = torch.zeros(nseg * r, width, device=dev)
+    dB = torch.zeros(nseg * width, r, device=dev)
+    dx = torch.zeros(rows, width, device=dev)
+    ops.lora_bwd(D(dy), D(x), t_gpu, D(A), D(Bm), dA, dB, dx=dx, scale=scale, p=p, seed=seed if p > 0 else 0,
+                 stream_base=sb)
+    _close(dA, A.grad, 2e-4, "lora dA")
+    _close(dB, Bm.grad, 2e-4, "lora dB")
+    _close(dx, xs.grad, 2e-4, "lora dx")
+
+
+def test_dropout_rate(dev):
+    """Philox keep-rate of the device stream is 1 - p (statistical sanity, 1e6 draws)."""
+    from clipfs import ops
+    rows, width = 2048, 512
+    x = torch.ones(rows, width, device=dev)
+    A = torch.ones(1, width, device=dev)
+    t = ops.lora_down(x, A, 1, 1, p=0.25, seed=99, stream_base=3)  # = kept_count / 0.75 per row
+    kept = (t.double().sum() * 0.75).item() / (rows * width)
+    assert abs(kept - 0.75) < 2e-3
+
+
+# ------------------------------------------------------------------ token assembly / head / loss
+def test_text_embed_gather_scatter(dev):
+    from clipfs import ops, synth
+    n, seq, width, vocab = 9, 16, 64, 512
+    ids = synth.synth_captions(n, seq, vocab, seed=3, max_len=9)
+    table, pos, ctx = _rand(vocab, width, seed=1), _rand(seq, width, seed=2), _rand(4, width, seed=3)
+    D = lambda t: t.float().to(dev)
+    x = ops.text_embed(ids.to(dev), D(table), D(pos))
+    _close(x.reshape(n, seq, width), table[ids] + pos, 1e-6, "text embed")
+    xc = ops.text_embed(ids.to(dev), D(table), D(pos), ctx=D(ctx))
+    want = table[ids].clone()
+    want[:, 1:5] = ctx
+    _close(xc.reshape(n, seq, width), want + pos, 1e-6, "text embed ctx")
+    rows, idx = ops.gather_eot(x, ids.to(dev))
+    eot = ids.argmax(dim=-1)
+    assert torch.equal(idx.cpu().long(), eot)
+    _close(rows, (table[ids] + pos)[torch.arange(n), eot], 1e-6, "gather eot")
+    dy = _rand(n, width, seed=5)
+    dx = ops.scatter_rows(D(dy), idx, seq).reshape(n, seq, width)
+    want = torch.zeros(n, seq, width, dtype=torch.float64)
+    want[torch.arange(n), eot] = dy
+    _close(dx, want, 1e-7, "scatter rows")
+    dctx = torch.zeros(4, width, device=dev)
+    g = _rand(n * seq, width, seed=6)
+    ops.text_ctx_grad(D(g), dctx, n, seq)
+    _close(dctx, g.reshape(n, seq, width)[:, 1:5].sum(0), 1e-5, "ctx grad")
+
+
+def test_vit_fill_special(dev):
+    from clipfs import ops
+    B, P, nv, width = 3, 4, 4, 128
+    L = 1 + P + nv
+    cls, pos, vpt = _rand(width, seed=1), _rand(1 + P, width, seed=2), _rand(nv, width, seed=3)
+    D = lambda t: t.float().to(dev)
+    x = torch.zeros(B * L, width, device=dev)
+    ops.vit_fill_special(x, D(cls), D(pos), D(vpt), B, L, P)
+    x = x.reshape(B, L, width).cpu().double()
+    assert torch.allclose(x[:, 0], (cls + pos[0]).float().double().expand(B, -1), atol=1e-6)
+    assert torch.allclose(x[:, 1 + P:], vpt.float().double().expand(B, -1, -1), atol=1e-6)
+    assert x[:, 1:1 + P].abs().max() == 0
+
+
+def test_l2norm_classmean_ce_topk(dev):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    D = lambda t: t.detach().float().to(dev)
+    x = _rand(37, 512, seed=1).requires_grad_()
+    y = O.l2_normalize(x)
+    yg, inv = ops.l2norm_fwd(D(x), save_inv=True)
+    _close(yg, y, 1e-6, "l2norm fwd")
+    dy = _rand(37, 512, seed=2)
+    y.backward(dy)
+    _close(ops.l2norm_bwd(D(dy), yg, inv), x.grad, 1e-5, "l2norm bwd")
+    # class mean over templates
+    Cn, T, w = 11, 3, 128
+    emb = _rand(Cn * T, w, seed=3).requires_grad_()
+    cls_idx = [c for c in range(Cn) for _ in range(T)]
+    want = O.class_text_features(emb, cls_idx, Cn).t()
+    got = ops.class_mean_fwd(D(emb), Cn, T)
+    _close(got, want, 1e-6, "class mean fwd")
+    dout = _rand(Cn, w, seed=4)
+    want.backward(dout)
+    _close(ops.class_mean_bwd(D(emb), D(dout), Cn, T), emb.grad, 1e-5, "class mean bwd")
+    # cross entropy
+    logits = (_rand(50, 403, seed=5) * 5).requires_grad_()
+    tgt = torch.from_numpy(np.random.RandomState(0).randint(0, 403, 50))
+    loss = O.jt_cross_entropy(logits, tgt)
+    loss.backward()
+    ls, dl, correct = ops.cross_entropy(D(logits), tgt.to(dev))
+    _close(ls / 50, loss.reshape(1), 1e-5, "ce loss")
+    _close(dl, logits.grad, 1e-6, "ce grad")
+    assert correct.item() == int((logits.argmax(1) == tgt).sum())
+    # top-k with ties: smaller index first
+    z = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0, 0.5, 2.0], [5.0, 5.0, 5.0, 5.0, 5.0, 5.0, 5.0]])
+    lab = ops.topk(z.to(dev), 5).cpu().long()
+    assert lab.tolist() == [[1, 2, 4, 3, 6], [0, 1, 2, 3, 4]]
+    assert torch.equal(lab, O.jt_topk(z, 5))
+    big = _rand(20, 403, seed=9).float()
+    assert torch.equal(ops.topk(big.to(dev), 5).cpu().long(), O.jt_topk(big, 5))
+
+
+def test_head_kernels(dev):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    D = lambda t: t.float().to(dev)
+    f = _rand(30, 512, seed=1)
+    s1, b1 = 1 + 0.1 * _rand(512, seed=2), 0.1 * _rand(512, seed=3)
+    w, b = _rand(403, 512, seed=4, scale=512 ** -0.5), 0.1 * _rand(403, seed=5)
+    z = ops.gemm_nt(ops.channel_affine(D(f), D(s1), D(b1)), D(w), bias=D(b))
+    want = O.channel_lp(f, s1, b1, w, b)
+    _close(z, want, 1e-4, "channel_lp")
+    _close(ops.logit_normalize(z), O.logit_normalize(want), 1e-4, "logit_normalize")
+
+
+def test_adamw(dev):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    n = 5000
+    p, g = _rand(n, seed=1) * 0.05, _rand(n, seed=2) * 1e-3
+    m, v = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    pd, md, vd = p.float().to(dev), m.float().to(dev), v.float().to(dev)
+    for step in (1, 2, 3):
+        gs = g * step
+        p, m, v = O.jt_adamw_step(p, gs, m, v, step)
+        ops.adamw(pd, gs.float().to(dev), md, vd, step)
+    _close(pd, p, 1e-6, "adamw p")
+    _close(md, m, 1e-8, "adamw m")
+
+
+# ------------------------------------------------------------------ MTA
+@pytest.mark.parametrize("V,d,Cn", [(65, 512, 403), (17, 64, 10)])
+def test_mta(dev, V, d, Cn):
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    n_img = 3
+    g = torch.Generator().manual_seed(4)
+    base = torch.randn(n_img, 1, d, generator=g, dtype=torch.float64)
+    feats = O.l2_normalize(base + 0.35 * torch.randn(n_img, V, d, generator=g, dtype=torch.float64))
+    text = O.l2_normalize(torch.randn(Cn, d, generator=g, dtype=torch.float64) + 0.5 * base[0])
+    mode, logits = ops.mta(feats.float().to(dev), text.float().to(dev))
+    for i in range(n_img):
+        wm = O.solve_mta(feats[i].float(), text.float().t(), return_mode=True)
+        wl = O.solve_mta(feats[i].float(), text.float().t(), return_mode=False)
+        _close(mode[i:i + 1], wm, 2e-5, "mta mode")
+        _close(logits[i:i + 1], wl, 2e-3, "mta logits")
+        assert torch.equal(ops.topk(logits[i:i + 1], 5).cpu().long(), O.jt_topk(wl, 5))
