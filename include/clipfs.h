@@ -130,8 +130,14 @@ int clipfs_vit_fill_special(float* x, const float* class_emb, const float* pos, 
  * (jclip/model.py:203-205; slow_pace.py:185-199,838). */
 int clipfs_text_embed(const int64_t* ids, const float* table, const float* pos, const float* ctx, int n_ctx,
                       float* x, int n, int seq, int width, void* stream);
-/* dctx[i,:] = sum_c dx[c, 1+i, :]  (gradient of the shared prompt tokens). */
-int clipfs_text_ctx_grad(const float* dx, float* dctx, int n, int seq, int width, int n_ctx, void* stream);
+/* dtok[i,:] += sum_c dx[c, first+i, :]: gradient of tokens shared by every sequence -- the text prompt
+ * ctx (first = 1, slow_pace.py:198-199) or the VPT tokens (first = 1 + patches, model1.py:192-194). */
+int clipfs_token_rows_grad(const float* dx, float* dtok, int n, int seq, int width, int n_tok, int first,
+                           void* stream);
+/* C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]: strided VALU product for the two tiny
+ * logits-backward products whose reduction runs over the classes (403: not 16-byte friendly). */
+int clipfs_matmul_small(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak,
+                        long sbk, long sbn, float alpha, void* stream);
 /* out[c,:] = x[c*seq + argmax_l ids[c,l], :]   (EOT row, jclip/model.py:213-214) ; idx_out optional */
 int clipfs_gather_eot(const float* x, const int64_t* ids, float* out, int32_t* idx_out, int n, int seq,
                       int width, void* stream);

@@ -73,7 +73,8 @@ SIGNATURES = {
     "clipfs_lora_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _p, _p]),
     "clipfs_vit_fill_special": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clipfs_text_embed": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
-    "clipfs_text_ctx_grad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "clipfs_token_rows_grad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "clipfs_matmul_small": (_i, [_p, _p, _p, _i, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long, _f, _p]),
     "clipfs_gather_eot": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_scatter_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "clipfs_l2norm_fwd": (_i, [_p, _p, _p, _i, _i, _p]),

@@ -163,9 +163,18 @@ def text_embed(ids, table, pos, ctx=None):
     return x
 
 
-def text_ctx_grad(dx, dctx, n, seq):
-    n_ctx, width = dctx.shape
-    check(_lib.load().clipfs_text_ctx_grad(_p(dx), _p(dctx), n, seq, width, n_ctx, _stream()), "text_ctx_grad")
+def token_rows_grad(dx, dtok, n, seq, first):
+    n_tok, width = dtok.shape
+    check(_lib.load().clipfs_token_rows_grad(_p(dx), _p(dtok), n, seq, width, n_tok, first, _stream()),
+          "token_rows_grad")
+
+
+def matmul_small(a, b, M, N, K, sam, sak, sbk, sbn, alpha=1.0, out=None):
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    check(_lib.load().clipfs_matmul_small(_p(a), _p(b), _p(out), M, N, K, sam, sak, sbk, sbn, alpha, _stream()),
+          "matmul_small")
+    return out
 
 
 def gather_eot(x, ids):

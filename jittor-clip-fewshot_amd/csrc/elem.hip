@@ -42,14 +42,14 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restri
   }
 }
 
-// dctx[i, :] = sum_c dx[c, 1 + i, :]
+// dctx[i, :] += sum_c dx[c, first + i, :]
 __global__ __launch_bounds__(256) void text_ctx_grad_kernel(const float* __restrict__ dx, float* __restrict__ dctx, int n,
-                                                            int seq, int width, int n_ctx) {
+                                                            int seq, int width, int n_ctx, int first) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_ctx * width) return;
   const int r = i / width, c = i % width;
   float acc = 0.f;
-  for (int k = 0; k < n; ++k) acc += dx[((size_t)k * seq + 1 + r) * width + c];
+  for (int k = 0; k < n; ++k) acc += dx[((size_t)k * seq + first + r) * width + c];
   dctx[i] += acc;
 }
 
@@ -369,6 +369,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   v[i] = vi;
 }
 
+// C[m,n] = alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]   (tiny products whose reduction dim is
+// not 16-byte friendly, e.g. over the 403 classes in the logits backward)
+__global__ __launch_bounds__(256) void matmul_small_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                           float* __restrict__ C, int M, int N, int K, long sam, long sak,
+                                                           long sbk, long sbn, float alpha) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i % N);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(A[m * sam + k * sak], B[k * sbk + n * sbn], acc);
+  C[i] = alpha * acc;
+}
+
 static inline unsigned grid_for(size_t total) {
   size_t b = (total + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -399,10 +412,20 @@ extern "C" int clipfs_text_embed(const int64_t* ids, const float* table, const f
   return launch_status();
 }
 
-extern "C" int clipfs_text_ctx_grad(const float* dx, float* dctx, int n, int seq, int width, int n_ctx, void* stream) {
-  CLIPFS_REQUIRE(dx && dctx && n > 0 && n_ctx > 0 && n_ctx < seq && width > 0, "text_ctx_grad: bad args");
+extern "C" int clipfs_token_rows_grad(const float* dx, float* dctx, int n, int seq, int width, int n_ctx, int first,
+                                      void* stream) {
+  CLIPFS_REQUIRE(dx && dctx && n > 0 && n_ctx > 0 && first >= 0 && first + n_ctx <= seq && width > 0, "token_rows_grad: bad args");
   hipLaunchKernelGGL(text_ctx_grad_kernel, dim3((n_ctx * width + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, dctx,
-                     n, seq, width, n_ctx);
+                     n, seq, width, n_ctx, first);
+  return launch_status();
+}
+
+extern "C" int clipfs_matmul_small(const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak,
+                                   long sbk, long sbn, float alpha, void* stream) {
+  CLIPFS_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "matmul_small: bad args");
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(matmul_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, B, C,
+                     M, N, K, sam, sak, sbk, sbn, alpha);
   return launch_status();
 }
 

@@ -7,9 +7,9 @@ namespace clipfs {
 
 constexpr int LN_MAX_CHUNKS = 8;  // 8 * 64 lanes * 4 floats = width <= 2048
 
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int ldx,  // x may alias y (in place)
                                                             const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            const float* __restrict__ beta, float* y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                             int rows, int width, float eps) {
   const int lane = threadIdx.x & 63;

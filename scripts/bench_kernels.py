@@ -1,0 +1,64 @@
+"""Micro-benchmarks of the hot kernels at the path's shapes (cfg-2: B=256, L=50, d=768; text 403x77, d=512).
+Prints achieved TFLOP/s (GEMM, vs 157.3 fp32-MFMA peak) or GB/s (memory-bound kernels, vs ~8 TB/s)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "jittor-clip-fewshot_amd"))
+from clipfs import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    shapes = [("qkv", 12800, 2304, 768), ("out", 12800, 768, 768), ("fc", 12800, 3072, 768), ("proj", 12800, 768, 3072),
+              ("t_qkv", 31031, 1536, 512), ("t_out", 31031, 512, 512), ("t_fc", 31031, 2048, 512),
+              ("t_proj", 31031, 512, 2048), ("sq4096", 4096, 4096, 4096)]
+    for name, M, N, K in shapes:
+        a = torch.randn(M, K, device=dev)
+        b = torch.randn(N, K, device=dev)
+        out = torch.empty(M, N, device=dev)
+        t = timeit(lambda: ops.gemm_nt(a, b, out))
+        print(f"gemm {name:7s} M={M} N={N} K={K}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:6.1f} TFLOP/s  ({2*M*N*K/t/157.3e12*100:.1f}% of fp32 MFMA peak)")
+    x = torch.randn(12800, 768, device=dev)
+    g = torch.ones(768, device=dev)
+    b = torch.zeros(768, device=dev)
+    t = timeit(lambda: ops.layernorm_fwd(x, g, b))
+    print(f"layernorm 12800x768: {t*1e6:.1f} us  {2*x.numel()*4/t/1e9:.0f} GB/s")
+    qkv = torch.randn(12800, 2304, device=dev)
+    t = timeit(lambda: ops.attention_fwd(qkv, 256, 50, 12, False))
+    print(f"attention fwd B=256 L=50 H=12: {t*1e6:.1f} us")
+    do = torch.randn(12800, 768, device=dev)
+    t = timeit(lambda: ops.attention_bwd(qkv, do, 256, 50, 12, False))
+    print(f"attention bwd B=256 L=50 H=12: {t*1e6:.1f} us")
+    qkv = torch.randn(31031, 1536, device=dev)
+    t = timeit(lambda: ops.attention_fwd(qkv, 403, 77, 8, True))
+    print(f"attention fwd B=403 L=77 H=8 causal: {t*1e6:.1f} us")
+    do = torch.randn(31031, 512, device=dev)
+    t = timeit(lambda: ops.attention_bwd(qkv, do, 403, 77, 8, True))
+    print(f"attention bwd B=403 L=77 H=8 causal: {t*1e6:.1f} us")
+    A = torch.randn(12, 768, device=dev)
+    t = timeit(lambda: ops.lora_down(x, A, 4, 3))
+    print(f"lora_down 12800x768 r=4x3: {t*1e6:.1f} us")
+    t = timeit(lambda: ops.lora_down(x, A, 4, 3, p=0.25, seed=7))
+    print(f"lora_down +dropout: {t*1e6:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,321 @@
+"""End-to-end parity of the HIP engine (through the jclip / lora_train_vlp drop-in API) against the CPU
+oracle on the same seeded inputs.  Tolerances: features 2e-5 abs (unit-scale values), training logits
+(100 x cosine) 1e-3 abs -- the north-star tolerance -- and top-5 labels identical; gradients 1e-4 relative
+to the largest gradient entry (fp32 engine vs fp64 oracle)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _args(cfg_name="ViT-B/32", params=("q", "k", "v"), r=4, p=0.0, encoder="both", position="all"):
+    return types.SimpleNamespace(encoder=encoder, position=position, backbone=cfg_name, params=list(params), r=r,
+                                 alpha=1, dropout_rate=p)
+
+
+def _build(cfg, dev, seed=11, n_vpt=0):
+    from clipfs import synth
+    from jclip.model import build_model
+    sd = synth.synth_state_dict(cfg, seed=seed, perturb=True)
+    dd = {"vision_ctx": n_vpt} if n_vpt else None
+    return sd, build_model(sd, design_details=dd, device=dev)
+
+
+def _positions(cfg):
+    """LoRA block lists for a synthetic config: reuse the reference tables by clipping to the depth."""
+    return list(range(cfg.transformer_layers)), list(range(cfg.vision_layers))
+
+
+def _apply(model, cfg, args, lora_weights, monkey):
+    """apply_lora on a synthetic-depth model: patch the position tables to the model's depth."""
+    import lora_train_vlp as L
+    tb, vb = _positions(cfg)
+    monkey.setitem(L.INDEX_POSITIONS_TEXT, args.position, tb)
+    monkey.setitem(L.INDEX_POSITIONS_VISION.setdefault(args.backbone, {}), args.position, vb)
+    layers = L.apply_lora(args, model)
+    names = {"q": "q_proj", "k": "k_proj", "v": "v_proj", "o": "proj"}
+    with torch.no_grad():
+        for i, layer in enumerate(layers):
+            for p in args.params:
+                ab = lora_weights[f"layer_{i}"][names[p]]
+                m = getattr(layer, names[p])
+                m.w_lora_A.copy_(torch.from_numpy(ab["w_lora_A"]))
+                m.w_lora_B.copy_(torch.from_numpy(ab["w_lora_B"]))
+    return layers
+
+
+def _oracle_lora(lora_weights, cfg, dtype=torch.float64, requires_grad=False):
+    tb, vb = _positions(cfg)
+    conv = lambda d: {p: {k: torch.from_numpy(v).to(dtype).requires_grad_(requires_grad) for k, v in ab.items()}
+                      for p, ab in d.items()}
+    text = {b: conv(lora_weights[f"layer_{i}"]) for i, b in enumerate(tb)}
+    vis = {b: conv(lora_weights[f"layer_{len(tb) + i}"]) for i, b in enumerate(vb)}
+    return text, vis
+
+
+def _err(got, want):
+    return (got.detach().double().cpu() - want.detach().double().cpu()).abs().max().item()
+
+
+@pytest.mark.parametrize("cfg_name", ["TINY", "SMALL"])
+def test_zero_shot_towers(dev, cfg_name):
+    from clipfs import synth
+    from oracle import clip_oracle as O
+    cfg = getattr(synth, cfg_name)
+    sd, model = _build(cfg, dev)
+    img = synth.synth_images(5, cfg.image_resolution, seed=3)
+    txt = synth.synth_captions(7, cfg.context_length, cfg.vocab_size, seed=4, max_len=cfg.context_length - 3)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        fi = model.encode_image(img.to(dev))
+        ft = model.encode_text(txt.to(dev))
+        li, lt = model(img.to(dev), txt.to(dev))
+        wi, wt = O.encode_image(sd64, img.double()), O.encode_text(sd64, txt)
+        wl, _ = O.clip_forward(sd64, img.double(), txt)
+    assert _err(fi, wi) < 2e-5 and _err(ft, wt) < 2e-5
+    assert _err(li, wl) < 1e-3 and _err(lt, wl.t()) < 1e-3
+
+
+@pytest.mark.parametrize("params", [("q", "k", "v"), ("q", "v"), ("q", "k", "v", "o")])
+def test_lora_forward(dev, monkeypatch, params):
+    from clipfs import synth
+    from oracle import clip_oracle as O
+    cfg = synth.SMALL
+    sd, model = _build(cfg, dev)
+    args = _args("small", params=params, r=4)
+    lw = synth.synth_lora(cfg, 4, seed=5, params=params)
+    _apply(model, cfg, args, lw, monkeypatch)
+    tl, vl = _oracle_lora(lw, cfg)
+    img = synth.synth_images(4, cfg.image_resolution, seed=3)
+    txt = synth.synth_captions(6, cfg.context_length, cfg.vocab_size, seed=4, max_len=12)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    s = O.lora_scaling(1, 4)
+    with torch.no_grad():
+        fi, ft = model.encode_image(img.to(dev)), model.encode_text(txt.to(dev))
+        wi = O.encode_image(sd64, img.double(), vl, s)
+        wt = O.encode_text(sd64, txt, tl, s)
+        zi = O.encode_image(sd64, img.double())
+    assert _err(fi, wi) < 2e-5 and _err(ft, wt) < 2e-5
+    assert _err(wi, zi) > 1e-3, "adapter must change the features (test is vacuous otherwise)"
+
+
+@pytest.mark.parametrize("p,with_ctx,params", [(0.0, False, ("q", "k", "v")), (0.25, False, ("q", "k", "v")),
+                                                (0.0, True, ("q", "k", "v", "o")), (0.25, True, ("q", "v"))])
+def test_train_step_gradients(dev, monkeypatch, p, with_ctx, params):
+    """loss, logits and every LoRA / prompt gradient of one run_lora step vs fp64 autograd on the oracle;
+    then the AdamW update of the flat buffer."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    from clipfs.engine import _mix_seed
+    from oracle import clip_oracle as O
+    cfg = synth.SMALL
+    sd, model = _build(cfg, dev)
+    args = _args("small", params=params, r=4, p=p)
+    lw = synth.synth_lora(cfg, 4, seed=5, params=params)
+    layers = _apply(model, cfg, args, lw, monkeypatch)
+    L.mark_only_lora_as_trainable(model)
+    B, Cn = 6, 9
+    img = synth.synth_images(B, cfg.image_resolution, seed=3)
+    cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=4, max_len=12)
+    tgt = synth.synth_labels(B, Cn, seed=2)
+    ctx_param = None
+    if with_ctx:
+        ctx_param = torch.nn.Parameter(sd["token_embedding.weight"][[5, 6, 7, 8]].clone().to(dev))
+    model.train()
+    tr = L.LoRATrainer(model, prompt_ctx=ctx_param)
+    tr.flat.zero_grad()
+    loss_sum, correct, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+    seed = _mix_seed(model.engine.seed_base, model.engine.step)
+
+    # ---- oracle (fp64 autograd) ----
+    sd64 = {k: v.double() for k, v in sd.items()}
+    tl, vl = _oracle_lora(lw, cfg, requires_grad=True)
+    names = {"q": "q_proj", "k": "k_proj", "v": "v_proj", "o": "proj"}
+
+    def drops(width, seq, n, layers_n, stream0):
+        if p == 0:
+            return None
+        out = {}
+        for l in range(layers_n):
+            d = {}
+            for s, pr in enumerate(("q", "k", "v", "o")):
+                if pr in params:
+                    keep = O.dropout_keep_mask(seed, stream0 + 4 * l + s, n * seq, width, p)
+                    m = torch.from_numpy(keep).double() / (1 - p)
+                    # engine rows are (b, l); the oracle is sequence-first [L, N, d]
+                    d[names[pr]] = m.reshape(n, seq, width).permute(1, 0, 2)
+            out[l] = d
+        return out
+
+    vtok = cfg.vision_tokens
+    td = drops(cfg.transformer_width, cfg.context_length, Cn, cfg.transformer_layers, 0)
+    vd = drops(cfg.vision_width, vtok, B, cfg.vision_layers, 1000)
+    octx = ctx_param.detach().double().cpu().requires_grad_() if with_ctx else None
+    loss, wlogits = O.train_step_loss(sd64, img.double(), cap, tgt, tl, vl, O.lora_scaling(1, 4), text_drops=td,
+                                      vis_drops=vd, ctx=octx, text_chunk=Cn)
+    loss.backward()
+    assert _err(logits, wlogits) < 1e-3
+    assert abs(loss_sum.item() / B - loss.item()) < 1e-4
+    assert correct.item() == int((wlogits.argmax(1) == tgt).sum())
+    assert torch.equal(L.ops.topk(logits, 5).cpu().long(), O.jt_topk(wlogits.float(), 5))
+
+    # gradients, layer by layer in apply_lora order (text blocks then vision blocks)
+    gmax = max(t.grad.abs().max().item() for blk in list(tl.values()) + list(vl.values()) for ab in blk.values()
+               for t in ab.values())
+    worst = 0.0
+    for i, layer in enumerate(layers):
+        blk = (list(tl.values()) + list(vl.values()))[i]
+        pairs = dict((id(prm), g) for prm, g in layer.trainable_pairs())
+        for pr in params:
+            m = getattr(layer, names[pr])
+            for nm, prm in (("w_lora_A", m.w_lora_A), ("w_lora_B", m.w_lora_B)):
+                worst = max(worst, _err(pairs[id(prm)], blk[names[pr]][nm].grad))
+    assert worst < 1e-4 * max(gmax, 1e-3), f"LoRA grad err {worst:.3e} vs scale {gmax:.3e}"
+    if with_ctx:
+        assert _err(ctx_param.grad_slot, octx.grad) < 1e-4 * max(octx.grad.abs().max().item(), 1e-3)
+
+    # ---- AdamW on the flat buffer ----
+    p0 = tr.flat.params.detach().clone().double().cpu()
+    g0 = tr.flat.grads.detach().clone().double().cpu()
+    tr.optimizer_step()
+    want, _, _ = O.jt_adamw_step(p0, g0, torch.zeros_like(p0), torch.zeros_like(p0), 1)
+    assert _err(tr.flat.params, want) < 1e-6
+
+
+def test_vpt_gradients(dev, monkeypatch):
+    """shallow VPT tokens (jclip/model1.py:192-194): forward parity and d loss / d VPT."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    from oracle import clip_oracle as O
+    cfg = synth.SMALL
+    sd, model = _build(cfg, dev, n_vpt=4)
+    args = _args("small", r=4)
+    lw = synth.synth_lora(cfg, 4, seed=5)
+    _apply(model, cfg, args, lw, monkeypatch)
+    B, Cn = 5, 7
+    img = synth.synth_images(B, cfg.image_resolution, seed=3)
+    cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=4, max_len=12)
+    tgt = synth.synth_labels(B, Cn, seed=2)
+    model.eval()
+    tr = L.LoRATrainer(model)
+    tr.flat.zero_grad()
+    _, _, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    tl, vl = _oracle_lora(lw, cfg)
+    vpt = model.visual.VPT.detach().double().cpu().requires_grad_()
+    s = O.lora_scaling(1, 4)
+    emb = O.encode_text(sd64, cap, tl, s)
+    txt = O.class_text_features(emb, list(range(Cn)), Cn)
+    fi = O.encode_image(sd64, img.double(), vl, s, vpt=vpt)
+    wl = O.train_logits(fi, txt)
+    O.jt_cross_entropy(wl, tgt).backward()
+    assert _err(logits, wl) < 1e-3
+    assert _err(model.visual.VPT.grad_slot, vpt.grad) < 1e-4 * max(vpt.grad.abs().max().item(), 1e-3)
+
+
+def test_autograd_api(dev, monkeypatch):
+    """The drop-in style of the reference loop: encode_text / encode_image / normalise / logits /
+    cross entropy / backward() -- gradients land in ``param.grad`` of the LoRA parameters."""
+    import lora_train_vlp as L
+    from clipfs import engine as E
+    from clipfs import synth
+    cfg = synth.SMALL
+    sd, model = _build(cfg, dev)
+    args = _args("small", r=4)
+    lw = synth.synth_lora(cfg, 4, seed=5)
+    layers = _apply(model, cfg, args, lw, monkeypatch)
+    L.mark_only_lora_as_trainable(model)
+    params = L.get_lora_parameters(model)
+    assert len(params) == 6 * (cfg.transformer_layers + cfg.vision_layers)
+    B, Cn = 6, 9
+    img = synth.synth_images(B, cfg.image_resolution, seed=3).to(dev)
+    cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=4, max_len=12).to(dev)
+    tgt = synth.synth_labels(B, Cn, seed=2).to(dev)
+    model.eval()
+    emb = model.encode_text(cap)
+    txt = E.class_mean(emb, Cn, 1)
+    fi = E.l2_normalize(model.encode_image(img))
+    loss = E.cross_entropy_loss(E.cosine_logits(fi, txt, 100.0), tgt)
+    loss.backward()
+    # same numbers as the fused trainer path
+    tr = L.LoRATrainer(model)
+    grads_api = {}
+    for layer in layers:
+        for prm, _ in layer.trainable_pairs():
+            pass
+    api = [p.grad.clone() for p in params]
+    tr.flat.zero_grad()
+    ls, _, _ = tr.forward_backward(img, cap, tgt)
+    assert abs(ls.item() / B - loss.item()) < 1e-5
+    new_params = L.get_lora_parameters(model)
+    slot = {}
+    for layer in layers:
+        for prm, g in layer.trainable_pairs():
+            slot[id(prm)] = g
+    for a, prm in zip(api, new_params):
+        assert _err(a, slot[id(prm)]) < 1e-6
+
+
+def test_vit_b32_full_size(dev, monkeypatch):
+    """Full ViT-B/32 + the reference's shipped trained LoRA checkpoint (tests/golden/lora_weights.pkl)
+    on cfg-1 sized inputs (8 images, 16 captions): logits within 1e-3 of the fp64 oracle, top-5 identical."""
+    import os
+    import lora_train_vlp as L
+    from clipfs import synth
+    from oracle import clip_oracle as O
+    cfg = synth.VIT_B32
+    sd, model = _build(cfg, dev, seed=1234)
+    args = _args("ViT-B/32", r=4, p=0.25)
+    layers = L.apply_lora(args, model)
+    golden = os.path.join(os.path.dirname(__file__), "golden", "lora_weights.pkl")
+    L.load_lora(args, layers, golden)
+    from clipfs import safe_pkl
+    ck = safe_pkl.load(golden)
+    tl, vl = O.split_lora_checkpoint(ck["weights"], "both", "all", "ViT-B/32")
+    B, Cn = 8, 16
+    img = synth.synth_images(B, 224, seed=0)
+    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=1)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    s = O.lora_scaling(1, 4)
+    model.eval()
+    with torch.no_grad():
+        fi = model.encode_image(img.to(dev))
+        ft = model.encode_text(cap.to(dev))
+        logits = L.ops.gemm_nt(L.ops.l2norm_fwd(fi), L.ops.l2norm_fwd(ft), alpha=100.0)
+        wi = O.encode_image(sd64, img.double(), vl, s)
+        wt = O.encode_text(sd64, cap, tl, s)
+        wl = 100.0 * O.l2_normalize(wi) @ O.l2_normalize(wt).t()
+    assert _err(logits, wl) < 1e-3, _err(logits, wl)
+    assert torch.equal(L.ops.topk(logits, 5).cpu().long(), O.jt_topk(wl.float(), 5))
+
+
+def test_save_load_roundtrip(dev, monkeypatch, tmp_path):
+    import lora_train_vlp as L
+    from clipfs import synth
+    cfg = synth.TINY
+    _, model = _build(cfg, dev)
+    args = _args("tiny", r=4)
+    lw = synth.synth_lora(cfg, 4, seed=9)
+    layers = _apply(model, cfg, args, lw, monkeypatch)
+    path = str(tmp_path / "lora_weights1" / "lora_weights.pkl")
+    L.save_lora(args, 0, layers, save_path=path)
+    _, model2 = _build(cfg, dev)
+    layers2 = _apply(model2, cfg, args, synth.synth_lora(cfg, 4, seed=10), monkeypatch)
+    L.load_lora(args, layers2, path)
+    for a, b in zip(layers, layers2):
+        assert torch.equal(a.lora_A_qkv, b.lora_A_qkv) and torch.equal(a.lora_B_qkv, b.lora_B_qkv)
+    bad = _args("tiny", r=8)
+    with pytest.raises(ValueError):
+        L.load_lora(bad, layers2, path)
+    with pytest.raises(FileNotFoundError):
+        L.load_lora(args, layers2, path + ".missing")

@@ -217,10 +217,10 @@ def test_text_embed_gather_scatter(dev):
     dx = ops.scatter_rows(D(dy), idx, seq).reshape(n, seq, width)
     want = torch.zeros(n, seq, width, dtype=torch.float64)
     want[torch.arange(n), eot] = dy
-    _close(dx, want, 1e-7, "scatter rows")
+    _close(dx, want, 1e-6, "scatter rows")
     dctx = torch.zeros(4, width, device=dev)
     g = _rand(n * seq, width, seed=6)
-    ops.text_ctx_grad(D(g), dctx, n, seq)
+    ops.token_rows_grad(D(g), dctx, n, seq, 1)
     _close(dctx, g.reshape(n, seq, width)[:, 1:5].sum(0), 1e-5, "ctx grad")
 
 
