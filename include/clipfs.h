@@ -77,6 +77,12 @@ typedef struct clipfs_gemm_args {
   int img_res, patch, out_tokens; /* a_mode 1 */
 } clipfs_gemm_args;
 int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
+/* Diagnostics for bench.py's roofline leg (never enabled inside a timed region): while enabled, every
+ * GEMM launch of the calling thread is bracketed by HIP events on its launch stream;
+ * clipfs_gemm_timing_collect synchronises on them and returns the summed kernel time, the summed
+ * algorithmic FLOPs (2*M*N*K) and the number of launches since the last collect. */
+int clipfs_gemm_timing(int enable);
+int clipfs_gemm_timing_collect(double* total_ms, double* total_flops, int* launches);
 
 /* ------------------------------------------------------------- LayerNorm --
  * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim (biased var).

@@ -64,6 +64,8 @@ SIGNATURES = {
     "clipfs_abi_version": (_i, []),
     "clipfs_last_error": (C.c_char_p, []),
     "clipfs_gemm_nt": (_i, [C.POINTER(GemmArgs), _p]),
+    "clipfs_gemm_timing": (_i, [_i]),
+    "clipfs_gemm_timing_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "clipfs_layernorm_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "clipfs_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_attention_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -16,6 +16,8 @@
 // (K % 32 != 0) is zero filled.  Epilogue order is documented in include/clipfs.h.
 #include "common.h"
 
+#include <vector>
+
 namespace clipfs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -217,6 +219,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   }
 }
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream around every
+// GEMM while enabled.  Off by default; never on in the timed region.
+struct TimedLaunch {
+  hipEvent_t start, stop;
+  double flops;
+};
+static thread_local bool g_timing = false;
+static thread_local std::vector<TimedLaunch>* g_timed = nullptr;
+
 template <int BM, int BN>
 static int launch(const GemmParams& p, hipStream_t stream) {
   const int mb = (p.a.M + BM - 1) / BM;
@@ -227,13 +238,52 @@ static int launch(const GemmParams& p, hipStream_t stream) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  TimedLaunch tl;
+  if (g_timing) {
+    (void)hipEventCreate(&tl.start);
+    (void)hipEventCreate(&tl.stop);
+    tl.flops = 2.0 * p.a.M * (double)p.a.N * p.a.K;
+    (void)hipEventRecord(tl.start, stream);
+  }
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
+  if (g_timing) {
+    (void)hipEventRecord(tl.stop, stream);
+    if (!g_timed) g_timed = new std::vector<TimedLaunch>();
+    g_timed->push_back(tl);
+  }
   return launch_status();
 }
 
 }  // namespace clipfs
 
 using namespace clipfs;
+
+extern "C" int clipfs_gemm_timing(int enable) {
+  g_timing = enable != 0;
+  return CLIPFS_OK;
+}
+
+extern "C" int clipfs_gemm_timing_collect(double* total_ms, double* total_flops, int* launches) {
+  double ms = 0.0, fl = 0.0;
+  int n = 0;
+  if (g_timed) {
+    for (TimedLaunch& t : *g_timed) {
+      float e = 0.f;
+      if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&e, t.start, t.stop) == hipSuccess) {
+        ms += e;
+        fl += t.flops;
+        ++n;
+      }
+      (void)hipEventDestroy(t.start);
+      (void)hipEventDestroy(t.stop);
+    }
+    g_timed->clear();
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  return CLIPFS_OK;
+}
 
 extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
   CLIPFS_REQUIRE(args != nullptr, "gemm: null args");

@@ -446,7 +446,9 @@ class LoRATrainer:
     gradient buffer is summed with one all-reduce (losses are pre-scaled by B_local / B_global)."""
 
     def __init__(self, model, lr: float = 2e-4, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
-                 logit_scale: float = 100.0, prompt_ctx: Optional[nn.Parameter] = None, process_group=None):
+                 logit_scale: float = 100.0, prompt_ctx: Optional[nn.Parameter] = None, process_group=None,
+                 shard_text: bool = True):
+        from clipfs import dist as D
         self.model = model
         extra = []
         if prompt_ctx is not None:
@@ -459,22 +461,29 @@ class LoRATrainer:
         self.logit_scale = logit_scale
         self.t = 0
         self.pg = process_group
-        self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world = torch.distributed.get_world_size(process_group)
+        self.rank, self.world = D.world_info(process_group)
+        self.shard_text = shard_text and self.world > 1
 
     def forward_backward(self, images, captions, target, templates_per_class: int = 1, global_batch: Optional[int] = None):
-        """Accumulates gradients into the flat buffer; returns (loss_sum_local [1], correct [1], logits)."""
+        """``images`` / ``target`` are THIS RANK's shard of the batch, ``captions`` the full caption table
+        [C * t, 77] (class major).  Accumulates gradients into the flat buffer; returns
+        (loss_sum_local [1], correct_local [1], logits_local [B_local, C])."""
+        from clipfs import dist as D
         m = self.model
         eng = m.engine
-        train = m.training
-        seed = eng.next_seed() if train else 0
+        seed = eng.next_seed() if m.training else 0
         B = images.shape[0]
         gb = global_batch or B * self.world
-        n_cap = captions.shape[0]
-        classes = n_cap // templates_per_class
-        emb, tctx = eng.text_forward(captions, self.prompt_ctx, True, seed)
-        txt = ops.class_mean_fwd(emb, classes, templates_per_class)
+        t = templates_per_class
+        classes = captions.shape[0] // t
+        c_lo, c_hi = D.shard_bounds(classes, self.rank, self.world) if self.shard_text else (0, classes)
+        emb = tctx = None
+        if c_hi > c_lo:
+            emb, tctx = eng.text_forward(captions[c_lo * t:c_hi * t], self.prompt_ctx, True, seed)
+            txt = ops.class_mean_fwd(emb, c_hi - c_lo, t)
+        if self.shard_text:
+            txt = D.allgather_rows(txt if c_hi > c_lo else None, c_lo, c_hi, classes, m.embed_dim, self.flat.params,
+                                   self.pg)
         feat, ictx = eng.vit_forward(images, True, seed)
         img_n, inv = ops.l2norm_fwd(feat, save_inv=True)
         logits = ops.gemm_nt(img_n, txt, alpha=self.logit_scale)
@@ -483,17 +492,26 @@ class LoRATrainer:
         d_img_n = ops.matmul_small(dl, txt, B, d, classes, classes, 1, d, 1, self.logit_scale)
         d_txt = ops.matmul_small(dl, img_n, classes, d, B, 1, classes, d, 1, self.logit_scale)
         eng.vit_backward(ictx, ops.l2norm_bwd(d_img_n, img_n, inv))
-        d_emb = ops.class_mean_bwd(emb, d_txt, classes, templates_per_class)
-        slot = None if self.prompt_ctx is None else self.prompt_ctx.grad_slot
-        eng.text_backward(tctx, d_emb, slot)
+        if self.shard_text:
+            D.allreduce_sum_(d_txt, self.pg)  # every rank needs the batch-total gradient of its classes
+        if c_hi > c_lo:
+            d_emb = ops.class_mean_bwd(emb, d_txt[c_lo:c_hi].contiguous(), c_hi - c_lo, t)
+            slot = None if self.prompt_ctx is None else self.prompt_ctx.grad_slot
+            eng.text_backward(tctx, d_emb, slot)
         return loss_sum, correct, logits
 
     def optimizer_step(self):
+        from clipfs import dist as D
+        grad_scale = 1.0
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat.grads, group=self.pg)
+            D.allreduce_sum_(self.flat.grads, self.pg)
+            if not self.shard_text:
+                # replicated text tower: every rank computed the same text gradients from ITS images only;
+                # the sum over ranks is already the batch total (d_txt is linear in the local dlogits).
+                pass
         self.t += 1
         ops.adamw(self.flat.params, self.flat.grads, self.flat.m, self.flat.v, self.t, self.lr, self.betas, self.eps,
-                  self.wd)
+                  self.wd, grad_scale)
 
     def step(self, images, captions, target, templates_per_class: int = 1):
         self.flat.zero_grad()
