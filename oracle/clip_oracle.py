@@ -648,6 +648,8 @@ class OracleTokenizer:
             regex.IGNORECASE)
 
     def _bpe(self, token: str) -> List[str]:
+        if token in ("<|startoftext|>", "<|endoftext|>"):  # pre-seeded cache entries, simple_tokenizer.py:83-86
+            return [token]
         word = list(token[:-1]) + [token[-1] + "</w>"]
         while len(word) > 1:
             best, best_rank = None, None

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors from the CPU oracle (fp64 truth, stored as fp64/fp32 .npz).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+The reference ships NO golden vectors and cannot run here (Jittor is not installable offline, SURVEY.md
+section 8c), so these pin the build's own restatement: tests/test_oracle_golden.py fails when the oracle
+drifts, tests/test_golden_gpu.py checks the HIP engine against the same files on the GPU box (where
+/root/reference does not exist).  Inputs are regenerated from seeds by clipfs.synth; only outputs (and
+small inputs that are not seed-derived) are stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "jittor-clip-fewshot_amd"))
+sys.path.insert(0, ROOT)
+
+from clipfs import safe_pkl, synth  # noqa: E402
+from oracle import clip_oracle as O  # noqa: E402
+
+SENTENCES = ["a diagram", "a dog", "a cat", "a photo of a", "A photo of a Bear, a type of animal.",
+             "it's  5 o'clock!!  café", "a photo of a stop sign.", "<|startoftext|>hello<|endoftext|>",
+             "Thu-vien_quoc-gia 12345 &amp; co."]
+
+
+def tiny_case():
+    """TINY CLIP + rank-4 LoRA(q,k,v,o) + 4 prompt tokens: logits, loss, every gradient."""
+    cfg = synth.TINY
+    sd = {k: v.double() for k, v in synth.synth_state_dict(cfg, seed=21, perturb=True).items()}
+    lw = synth.synth_lora(cfg, 4, seed=22, params=("q", "k", "v", "o"))
+    nt = cfg.transformer_layers
+    conv = lambda d: {p: {k: torch.from_numpy(v).double().requires_grad_() for k, v in ab.items()} for p, ab in d.items()}
+    tl = {b: conv(lw[f"layer_{b}"]) for b in range(nt)}
+    vl = {b: conv(lw[f"layer_{nt + b}"]) for b in range(cfg.vision_layers)}
+    B, Cn = 5, 7
+    img = synth.synth_images(B, cfg.image_resolution, seed=23).double()
+    cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=24, max_len=9)
+    tgt = synth.synth_labels(B, Cn, seed=25)
+    ctx = sd["token_embedding.weight"][[9, 10, 11, 12]].clone().requires_grad_()
+    loss, logits = O.train_step_loss(sd, img, cap, tgt, tl, vl, 0.5, ctx=ctx, text_chunk=3)
+    loss.backward()
+    out = {"logits": logits.detach().numpy(), "loss": np.array(loss.item()), "dctx": ctx.grad.numpy(),
+           "top5": O.jt_topk(logits.detach(), 5).numpy()}
+    for i, blk in enumerate(list(tl.values()) + list(vl.values())):
+        for p, ab in blk.items():
+            for k, t in ab.items():
+                out[f"grad.layer_{i}.{p}.{k}"] = t.grad.numpy()
+    with torch.no_grad():
+        out["img_feat"] = O.encode_image(sd, img, vl, 0.5).numpy()
+        out["txt_feat_zs"] = O.encode_text(sd, cap).numpy()
+    np.savez_compressed(os.path.join(HERE, "tiny_train_step.npz"), **out)
+
+
+def block_case():
+    """One full-size ViT-B/32 residual block (d=768, L=50, B=2) with the shipped LoRA of vision block 0."""
+    g = torch.Generator().manual_seed(31)
+    d, L, B, H = 768, 50, 2, 12
+    cfg = synth.VIT_B32
+    full = synth.synth_state_dict(cfg, seed=1234)
+    blk = {k: v.double() for k, v in O._block_params(full, "visual.transformer", 0).items()}
+    ck = safe_pkl.load(os.path.join(HERE, "lora_weights.pkl"))
+    _, vl = O.split_lora_checkpoint(ck["weights"], "both", "all", "ViT-B/32")
+    x = torch.randn(L, B, d, generator=g, dtype=torch.float64).float().double().requires_grad_()  # fp32-exact inputs
+    y = O.resblock_forward(x, blk, H, None, vl[0], 0.5)
+    dy = torch.randn(L, B, d, generator=g, dtype=torch.float64).float().double()
+    y.backward(dy)
+    np.savez_compressed(os.path.join(HERE, "vitb32_block0.npz"), x=x.detach().numpy().astype(np.float32),
+                        dy=dy.numpy().astype(np.float32), y=y.detach().numpy(), dx=x.grad.numpy())
+
+
+def mta_case():
+    g = torch.Generator().manual_seed(41)
+    V, d, Cn = 65, 512, 403
+    base = torch.randn(1, d, generator=g, dtype=torch.float64)
+    feats = O.l2_normalize(base + 0.35 * torch.randn(V, d, generator=g, dtype=torch.float64)).float()
+    text = O.l2_normalize(torch.randn(Cn, d, generator=g, dtype=torch.float64) + 0.5 * base).float()
+    logits, tr = O.solve_mta(feats, text.t(), return_trace=True)
+    mode = O.solve_mta(feats, text.t(), return_mode=True)
+    np.savez_compressed(os.path.join(HERE, "mta_v65.npz"), feats=feats.numpy(), text=text.numpy(),
+                        logits=logits.numpy(), mode=mode.numpy(), y=tr["y"].numpy(), bandwidth=tr["bandwidth"].numpy(),
+                        n_y=np.array(tr["n_y"]), n_m=np.array(tr["n_m"]), top5=O.jt_topk(logits, 5).numpy(),
+                        is_base=O.ood_is_base(logits).numpy())
+
+
+def tokenizer_case():
+    tk = O.OracleTokenizer(os.path.join(ROOT, "jittor-clip-fewshot_amd", "jclip", "bpe_simple_vocab_16e6.txt.gz"))
+    ids = tk.tokenize(SENTENCES).numpy()
+    names = [ln.split()[0] for ln in open(os.path.join(HERE, "classes.txt"))]
+    prompts = ["a photo of a " + (n.split("_", 1)[1] if "_" in n else n).replace("_", " ") + "." for n in names]
+    np.savez_compressed(os.path.join(HERE, "tokenizer_ids.npz"), sentences=np.array(SENTENCES), ids=ids,
+                        class_prompt_ids=tk.tokenize(prompts).numpy())
+
+
+def philox_case():
+    keep = O.dropout_keep_mask(0x1234ABCD5, 7, 5, 64, 0.25)
+    np.savez_compressed(os.path.join(HERE, "philox_mask.npz"), keep=keep)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    tiny_case()
+    block_case()
+    mta_case()
+    tokenizer_case()
+    philox_case()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,107 @@
+"""Host-side drop-in API without a GPU: model construction from a state dict (hyper-parameter inference,
+jclip/model.py:235-274), apply_lora placement / order, parameter filters, checkpoint schema and errors.
+Parameters live on the CPU here; no kernel is launched."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+
+def _args(**kw):
+    d = dict(encoder="both", position="all", backbone="ViT-B/32", params=["q", "k", "v"], r=4, alpha=1, dropout_rate=0.25)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+@pytest.fixture(scope="module")
+def b32():
+    from clipfs import synth
+    from jclip.model import build_model
+    sd = synth.synth_state_dict(synth.VIT_B32, seed=1)
+    sd = dict(sd, input_resolution=torch.tensor(224), context_length=torch.tensor(77), vocab_size=torch.tensor(49408))
+    return build_model(sd, device=torch.device("cpu"))
+
+
+def test_build_model_infers_hyperparameters(b32):
+    m = b32
+    assert m.visual.input_resolution == 224 and m.visual.patch_size == 32 and m.visual.width == 768
+    assert m.visual.transformer.layers == 12 and m.visual.transformer.heads == 12 and m.visual.tokens == 50
+    assert m.transformer.width == 512 and m.transformer.heads == 8 and m.transformer.layers == 12
+    assert m.context_length == 77 and m.vocab_size == 49408 and m.embed_dim == 512
+    assert m.dtype == torch.float32 and not m.training
+    assert type(m.transformer.resblocks[0].attn).__name__ == "MultiheadAttention"
+
+
+def test_apply_lora_order_filters_and_shipped_checkpoint(b32, golden_dir):
+    import lora_train_vlp as L
+    args = _args()
+    layers = L.apply_lora(args, b32)
+    assert len(layers) == 24
+    assert [l.embed_dim for l in layers] == [512] * 12 + [768] * 12  # text blocks first (lora_train_vlp.py:519-546)
+    assert L.apply_lora(args, b32) == []  # already adapted blocks are skipped (class-name check :526)
+    params = L.get_lora_parameters(b32)
+    assert len(params) == 144 and sum(p.numel() for p in params) == 368640
+    names = [n for n, _ in b32.named_parameters() if "lora_" in n]
+    assert "transformer.resblocks.0.attn.q_proj.w_lora_A" in names
+    assert "visual.transformer.resblocks.11.attn.v_proj.w_lora_B" in names
+    L.mark_only_lora_as_trainable(b32)
+    assert all(p.requires_grad == ("lora_" in n) for n, p in b32.named_parameters())
+    assert set(L.lora_state_dict(b32)) == set(names)
+    with pytest.raises(NotImplementedError):
+        L.mark_only_lora_as_trainable(b32, bias="all")
+    l0 = layers[0]
+    assert l0.scaling == 0.5 and l0.q_proj.r == 4  # alpha / sqrt(r)
+    assert torch.count_nonzero(l0.q_proj.w_lora_B) == 0  # B = 0 at init (:213)
+    assert l0.q_proj.w_lora_A.abs().max() <= 1 / np.sqrt(512) + 1e-7  # kaiming_uniform(a=sqrt 5) bound
+    # q/k/v weights are views of the packed in-projection (rows [0:d],[d:2d],[2d:3d], :395-409)
+    assert l0.k_proj.weight.data_ptr() == l0.qkv_weight[512:].data_ptr()
+    L.load_lora(args, layers, os.path.join(golden_dir, "lora_weights.pkl"))
+    from clipfs import safe_pkl
+    ck = safe_pkl.load(os.path.join(golden_dir, "lora_weights.pkl"))
+    assert np.array_equal(layers[13].v_proj.w_lora_B.detach().numpy(), ck["weights"]["layer_13"]["v_proj"]["w_lora_B"])
+    assert np.array_equal(layers[13].lora_A_qkv[4:8].numpy(), ck["weights"]["layer_13"]["k_proj"]["w_lora_A"])
+    for field, val in (("r", 8), ("alpha", 2), ("encoder", "text"), ("params", ["q"]), ("position", "up")):
+        with pytest.raises(ValueError, match="mismatch"):
+            L.load_lora(_args(**{field: val}), layers, os.path.join(golden_dir, "lora_weights.pkl"))
+    with pytest.raises(FileNotFoundError):
+        L.load_lora(args, layers, "/nonexistent/lora.pkl")
+
+
+def test_save_lora_schema_roundtrip(tmp_path):
+    import lora_train_vlp as L
+    from clipfs import safe_pkl, synth
+    from jclip.model import build_model
+    m = build_model(synth.synth_state_dict(synth.TINY, seed=2), device=torch.device("cpu"))
+    args = _args(backbone="tiny", position="bottom", params=["q", "v", "o"], r=2, encoder="vision")
+    L.INDEX_POSITIONS_VISION["tiny"] = {"bottom": [0, 1]}
+    try:
+        layers = L.apply_lora(args, m)
+    finally:
+        del L.INDEX_POSITIONS_VISION["tiny"]
+    assert len(layers) == 2 and layers[0].lora_mask == 1 | 4 | 8
+    with torch.no_grad():
+        layers[1].proj.w_lora_B.normal_()
+    path = str(tmp_path / "lora_weights1" / "lora_weights.pkl")
+    L.save_lora(args, 3, layers, save_path=path)
+    ck = safe_pkl.load(path)
+    assert ck["metadata"] == {"r": 2, "alpha": 1, "encoder": "vision", "params": ["q", "v", "o"], "position": "bottom"}
+    assert sorted(ck["weights"]["layer_1"]) == ["proj", "q_proj", "v_proj"]
+    assert np.array_equal(ck["weights"]["layer_1"]["proj"]["w_lora_B"], layers[1].proj.w_lora_B.detach().numpy())
+    assert type(layers[0].k_proj).__name__ == "_FrozenLinear"
+
+
+def test_engine_refuses_cpu_tensors(b32):
+    with pytest.raises((AssertionError, RuntimeError)):
+        b32.encode_image(torch.zeros(1, 3, 224, 224))
+
+
+def test_shard_bounds():
+    from clipfs.dist import shard_bounds
+    for n, w in ((403, 8), (256, 8), (7, 3), (3, 8)):
+        parts = [shard_bounds(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1
