@@ -15,8 +15,9 @@ tests / golden vectors.  What pins this oracle:
   * an independent second opinion: ``transformers.CLIPModel`` (OpenAI CLIP
     semantics) with locally initialised random weights
     (tests/test_oracle_vs_hf.py, CPU only);
-  * algebraic self checks (merged LoRA == additive LoRA at p=0, packed QKV ==
-    split q/k/v, LND == NLD, MTA with V=1 returns F[0], ...).
+  * known-answer tests (Random123 Philox4x32-10 vectors, published CLIP token ids)
+    and algebraic self checks (merged LoRA == additive LoRA at p=0, packed QKV ==
+    split q/k/v, caption chunking invariance, ...) in tests/test_oracle_golden.py.
 Jittor op semantics that cannot be verified offline are isolated in single,
 clearly named functions (``jt_layer_norm``, ``jt_cross_entropy``, ``jt_adamw_step``,
 ``jt_std``, ``jt_argsort_values``, ``jt_topk``).
