@@ -35,16 +35,32 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
     if (_rc != CLIPFS_OK) return _rc; \
   } while (0)
 
-// ---- wave64 reductions (cross-lane shuffles; no LDS) ----
+// ---- wave64 reductions: DPP butterfly inside each row of 16 lanes, row_bcast across rows, one
+// v_readlane of lane 63 to broadcast (no LDS crossbar: ds_bpermute shuffles cost ~6 dependent LDS round
+// trips per reduction, the DPP form ~6 VALU slots).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float identity, float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f<0xB1, 0xf>(0.f, v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xf>(0.f, v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xf>(0.f, v);  // row_half_mirror
+  v += dpp_f<0x140, 0xf>(0.f, v);  // row_mirror        -> every lane: sum of its row of 16
+  v += dpp_f<0x142, 0xa>(0.f, v);  // row_bcast:15 into rows 1,3
+  v += dpp_f<0x143, 0xc>(0.f, v);  // row_bcast:31 into rows 2,3 -> lanes 48..63: total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  const float ninf = -INFINITY;
+  v = fmaxf(v, dpp_f<0xB1, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x4E, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x141, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x140, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f<0x142, 0xa>(ninf, v));
+  v = fmaxf(v, dpp_f<0x143, 0xc>(ninf, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---- Philox4x32-10 dropout stream (bit-identical to oracle/clip_oracle.py:dropout_keep_mask) ----

@@ -16,22 +16,29 @@
 // (K % 32 != 0) is zero filled.  Epilogue order is documented in include/clipfs.h.
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <vector>
 
 namespace clipfs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // first-class vector: stays in VGPRs (HIP's float4 struct arrays went to scratch)
 
 struct GemmParams {
   clipfs_gemm_args a;
   int n_blocks_n;  // number of BN-wide column blocks
   int patches;     // a_mode 1: patches per image (G*G)
   int grid_g;      // a_mode 1: patches per side
+  int ablate;      // tuning aid (CLIPFS_GEMM_ABLATE): 1 no global prefetch, 2 no LDS store, 4 no barrier -- WRONG RESULTS
 };
 
 constexpr int BK = 32;
 
-template <int BM, int BN>
+// AMODE 0: dense A, K % 32 == 0 (the hot configuration: the K loop is pointer bumps + 16-byte loads only)
+// AMODE 1: patch im2col with patch == 32 (one K-step == one (channel, ky) image row segment)
+// AMODE 2: generic (dense with a K tail, or any patch size): per-element address arithmetic
+template <int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TM = BM / 64;            // 32x32 tiles per wave along M
@@ -45,9 +52,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int bid = blockIdx.x;
-  const int m0 = (bid / p.n_blocks_n) * BM;
-  const int n0 = (bid % p.n_blocks_n) * BN;
+  // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD, speed only),
+  // each XCD has a private 4 MB L2: give every XCD a CONTIGUOUS run of the tile list, and order the list in
+  // super-tiles of GM m-blocks x all n-blocks (m fastest) so the ~96 tiles an XCD runs at once share
+  // 16 A panels and 6 B panels instead of ~40 + 18 (FETCH_SIZE: DESIGN.md section 8).
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li;
+  }
+  constexpr int GM = 16;
+  const int nbn = p.n_blocks_n;
+  const int grp = tile / (GM * nbn);
+  const int rem = tile - grp * (GM * nbn);
+  const int mb_total = (g.M + BM - 1) / BM;
+  const int gm = min(GM, mb_total - grp * GM);  // the last group may be shorter
+  const int m0 = (grp * GM + rem % gm) * BM;
+  const int n0 = (rem / gm) * BN;
   const int M = g.M, N = g.N, K = g.K;
 
   // ---- staging addresses -------------------------------------------------------------------
@@ -58,12 +80,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   for (int i = 0; i < A_CHUNKS; ++i) {
     const int row = (tid >> 3) + 32 * i;
     const int m = min(m0 + row, M - 1);
-    if (g.a_mode == 0) {
-      a_src[i] = g.A + (size_t)m * g.lda;
+    if (AMODE == 0 || (AMODE == 2 && g.a_mode == 0)) {
+      a_src[i] = g.A + (size_t)m * g.lda + (AMODE == 0 ? kc * 4 : 0);
     } else {
       const int b = m / p.patches, pp = m - b * p.patches;
       const int py = pp / p.grid_g, px = pp - py * p.grid_g;
-      a_src[i] = g.A + ((size_t)b * 3 * g.img_res + (size_t)py * g.patch) * g.img_res + (size_t)px * g.patch;
+      a_src[i] = g.A + ((size_t)b * 3 * g.img_res + (size_t)py * g.patch) * g.img_res + (size_t)px * g.patch +
+                 (AMODE == 1 ? kc * 4 : 0);
     }
     a_lds[i] = row * BK + ((kc ^ ((row >> 1) & 7)) << 2);
   }
@@ -73,31 +96,37 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   for (int i = 0; i < B_CHUNKS; ++i) {
     const int row = (tid >> 3) + 32 * i;
     const int n = min(n0 + row, N - 1);
-    b_src[i] = g.B + (size_t)n * g.ldb;
+    b_src[i] = g.B + (size_t)n * g.ldb + (AMODE != 2 ? kc * 4 : 0);
     b_lds[i] = BM * BK + row * BK + ((kc ^ ((row >> 1) & 7)) << 2);
   }
 
-  float4 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
-  auto load_global = [&](int k0) {
-    const int k = k0 + kc * 4;
-    const bool k_ok = k < K;  // K % 4 == 0 is checked on the host
-    if (g.a_mode == 0) {
+  f32x4 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
+  auto load_global = [&](int kt) __attribute__((always_inline)) {
+    if (AMODE == 0) {
+      const int k0 = kt * BK;
 #pragma unroll
-      for (int i = 0; i < A_CHUNKS; ++i)
-        a_reg[i] = k_ok ? *reinterpret_cast<const float4*>(a_src[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + k0);
+#pragma unroll
+      for (int i = 0; i < B_CHUNKS; ++i) b_reg[i] = *reinterpret_cast<const f32x4*>(b_src[i] + k0);
+    } else if (AMODE == 1) {
+      // patch == 32 == BK: K-step kt is image row (c = kt / 32, ky = kt % 32) of every patch
+      const int k0 = kt * BK;
+      const size_t off = ((size_t)(kt >> 5) * g.img_res + (kt & 31)) * g.img_res;
+#pragma unroll
+      for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + off);
+#pragma unroll
+      for (int i = 0; i < B_CHUNKS; ++i) b_reg[i] = *reinterpret_cast<const f32x4*>(b_src[i] + k0);
     } else {
-      // k -> (channel, ky, kx); a 4-chunk never crosses a patch row when patch % 4 == 0
-      const int pp2 = g.patch * g.patch;
-      const int c = k / pp2, rem = k - c * pp2;
-      const int ky = rem / g.patch, kx = rem - ky * g.patch;
-      const size_t off = ((size_t)c * g.img_res + ky) * g.img_res + kx;
+      const int k = kt * BK + kc * 4;
+      const bool k_ok = k < K;  // K % 4 == 0 is checked on the host
+      if (g.a_mode == 0) {
 #pragma unroll
-      for (int i = 0; i < A_CHUNKS; ++i) {
-        if (!k_ok) {
-          a_reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if ((g.patch & 3) == 0) {
-          a_reg[i] = *reinterpret_cast<const float4*>(a_src[i] + off);
-        } else {
+        for (int i = 0; i < A_CHUNKS; ++i)
+          a_reg[i] = k_ok ? *reinterpret_cast<const f32x4*>(a_src[i] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const int pp2 = g.patch * g.patch;
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
           float t[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -106,20 +135,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
             const int ky2 = r2 / g.patch, kx2 = r2 - ky2 * g.patch;
             t[e] = kk < K ? a_src[i][((size_t)c2 * g.img_res + ky2) * g.img_res + kx2] : 0.f;
           }
-          a_reg[i] = make_float4(t[0], t[1], t[2], t[3]);
+          a_reg[i] = f32x4{t[0], t[1], t[2], t[3]};
         }
       }
-    }
 #pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i)
-      b_reg[i] = k_ok ? *reinterpret_cast<const float4*>(b_src[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < B_CHUNKS; ++i)
+        b_reg[i] = k_ok ? *reinterpret_cast<const f32x4*>(b_src[i] + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
-  auto store_lds = [&](int stage) {
+  auto store_lds = [&](int stage) __attribute__((always_inline)) {
     float* s = smem + stage * STAGE_FLOATS;
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) *reinterpret_cast<float4*>(s + a_lds[i]) = a_reg[i];
+    for (int i = 0; i < A_CHUNKS; ++i) *reinterpret_cast<f32x4*>(s + a_lds[i]) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) *reinterpret_cast<float4*>(s + b_lds[i]) = b_reg[i];
+    for (int i = 0; i < B_CHUNKS; ++i) *reinterpret_cast<f32x4*>(s + b_lds[i]) = b_reg[i];
   };
 
   // ---- fragment read addresses -----------------------------------------------------------------
@@ -140,37 +169,41 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (K + BK - 1) / BK;
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) load_global((kt + 1) * BK);
-    const float* s = smem + (kt & 1) * STAGE_FLOATS;
+  auto compute = [&](const float* s) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ch = (((2 * q + fh) ^ swz) << 2);
-      float4 av[TM], bv[TN];
+      f32x4 av[TM], bv[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) av[t] = *reinterpret_cast<const float4*>(s + a_frag[t] + ch);
+      for (int t = 0; t < TM; ++t) av[t] = *reinterpret_cast<const f32x4*>(s + a_frag[t] + ch);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) bv[t] = *reinterpret_cast<const float4*>(s + b_frag[t] + ch);
+      for (int t = 0; t < TN; ++t) bv[t] = *reinterpret_cast<const f32x4*>(s + b_frag[t] + ch);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const float ae = e == 0 ? av[i].x : e == 1 ? av[i].y : e == 2 ? av[i].z : av[i].w;
+          const float ae = av[i][e];
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const float be = e == 0 ? bv[j].x : e == 1 ? bv[j].y : e == 2 ? bv[j].z : bv[j].w;
+            const float be = bv[j][e];
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc[i][j], 0, 0, 0);
           }
         }
       }
     }
-    if (more) store_lds((kt + 1) & 1);
-    __syncthreads();
+  };
+  // prologue, steady state (prefetch unconditionally: the staged registers must stay in VGPRs), tail
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    if (!(p.ablate & 1)) load_global(kt + 1);  // global -> registers, one K-step ahead
+    __builtin_amdgcn_sched_barrier(0);         // keep the loads ABOVE the MFMAs (hipcc sinks them to the ds_write otherwise)
+    compute(smem + (kt & 1) * STAGE_FLOATS);   // 32 MFMAs per wave hide the load latency
+    if (!(p.ablate & 2)) store_lds((kt + 1) & 1);  // registers -> the other LDS stage
+    if (!(p.ablate & 4)) __syncthreads();
   }
+  compute(smem + ((nk - 1) & 1) * STAGE_FLOATS);
 
   // ---- epilogue ------------------------------------------------------------------------------
   // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -228,13 +261,13 @@ struct TimedLaunch {
 static thread_local bool g_timing = false;
 static thread_local std::vector<TimedLaunch>* g_timed = nullptr;
 
-template <int BM, int BN>
+template <int BM, int BN, int AMODE>
 static int launch(const GemmParams& p, hipStream_t stream) {
   const int mb = (p.a.M + BM - 1) / BM;
   const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, AMODE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -245,7 +278,7 @@ static int launch(const GemmParams& p, hipStream_t stream) {
     tl.flops = 2.0 * p.a.M * (double)p.a.N * p.a.K;
     (void)hipEventRecord(tl.start, stream);
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, AMODE>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
   if (g_timing) {
     (void)hipEventRecord(tl.stop, stream);
     if (!g_timed) g_timed = new std::vector<TimedLaunch>();
@@ -298,6 +331,8 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
   GemmParams p;
   p.a = a;
   p.patches = 0;
+  static const int ablate_cfg = getenv("CLIPFS_GEMM_ABLATE") ? atoi(getenv("CLIPFS_GEMM_ABLATE")) : 0;
+  p.ablate = ablate_cfg;
   p.grid_g = 0;
   if (a.a_mode == 0) {
     CLIPFS_REQUIRE((a.lda & 3) == 0 && a.lda >= a.K && aligned16(a.A), "gemm: lda must be a multiple of 4 and >= K, A 16-byte aligned");
@@ -317,6 +352,17 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // 64x128 tiles keep the tile count a large multiple of the CU count at the path's shapes
   // (M = 12800: 200 x N/128 tiles), 128x128 is used when there are plenty of tiles anyway.
+  static const int tile_cfg = getenv("CLIPFS_GEMM_TILE") ? atoi(getenv("CLIPFS_GEMM_TILE")) : 0;  // tuning aid
+  if (tile_cfg == 1 && a.a_mode == 0 && (a.K % BK) == 0) {
+    p.n_blocks_n = (a.N + 127) / 128;
+    return launch<128, 128, 0>(p, s);
+  }
+  if (tile_cfg == 2 && a.a_mode == 0 && (a.K % BK) == 0) {
+    p.n_blocks_n = (a.N + 63) / 64;
+    return launch<128, 64, 0>(p, s);
+  }
   p.n_blocks_n = (a.N + 127) / 128;
-  return launch<64, 128>(p, s);
+  if (a.a_mode == 0 && (a.K % BK) == 0) return launch<64, 128, 0>(p, s);
+  if (a.a_mode == 1 && a.patch == 32 && (a.img_res & 3) == 0) return launch<64, 128, 1>(p, s);
+  return launch<64, 128, 2>(p, s);
 }

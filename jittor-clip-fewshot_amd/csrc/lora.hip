@@ -67,34 +67,38 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const float* __restrict_
   }
 }
 
-// dt[m, s*r+j] = scale * sum_n dy[m, s*segw+n] * B[s*segw+n, j]     one wave per row
+// dt[m, s*r+j] = scale * sum_n dy[m, s*segw+n] * B[s*segw+n, j]     one wave per row, 16-byte loads:
+// a lane takes 4 consecutive n (one float4 of dy) and the 4 matching rows of B.
+template <int R>
 __global__ __launch_bounds__(256) void lora_dt_kernel(const float* __restrict__ dy, const float* __restrict__ B,
-                                                      float* __restrict__ dt, int rows, int segw, int r, int nseg,
+                                                      float* __restrict__ dt, int rows, int segw, int nseg,
                                                       unsigned seg_mask, float scale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* dr = dy + (size_t)row * nseg * segw;
-  float* out = dt + (size_t)row * nseg * r;
+  float* out = dt + (size_t)row * nseg * R;
   for (int s = 0; s < nseg; ++s) {
     if (!((seg_mask >> s) & 1u)) {
-      if (lane < r) out[s * r + lane] = 0.f;
+      if (lane < R) out[s * R + lane] = 0.f;
       continue;
     }
-    for (int j0 = 0; j0 < r; j0 += 4) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int n = lane; n < segw; n += 64) {
-        const float g = dr[s * segw + n];
-        const float* b = B + (size_t)(s * segw + n) * r + j0;
+    float acc[R];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          if (j0 + jj < r) acc[jj] = fmaf(g, b[jj], acc[jj]);
-      }
+    for (int j = 0; j < R; ++j) acc[j] = 0.f;
+    for (int n4 = lane; n4 < (segw >> 2); n4 += 64) {
+      const float4 g = *reinterpret_cast<const float4*>(dr + s * segw + 4 * n4);
+      const float* b = B + ((size_t)s * segw + 4 * n4) * R;
+      const float gv[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const float v = wave_sum(acc[jj]);
-        if (lane == 0 && j0 + jj < r) out[s * r + j0 + jj] = scale * v;
-      }
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < R; ++j) acc[j] = fmaf(gv[e], b[e * R + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const float v = wave_sum(acc[j]);
+      if (lane == 0) out[s * R + j] = scale * v;
     }
   }
 }
@@ -127,13 +131,13 @@ __global__ __launch_bounds__(256) void lora_db_partial_kernel(const float* __res
 }
 
 // dA partials: thread = 4 consecutive columns k of x; acc[s][j] over the slice's rows, dropout
-// multipliers regenerated from the Philox stream (never stored).
+// multipliers regenerated from the Philox stream (never stored).  One wave per (256 columns, row slice).
 template <int R, int NSEG>
-__global__ __launch_bounds__(256) void lora_da_partial_kernel(const float* __restrict__ x, const float* __restrict__ dt,
-                                                              float* __restrict__ part, int rows, int width,
-                                                              unsigned seg_mask, float p, uint64_t seed,
-                                                              uint32_t stream_base, int rows_per_slice) {
-  const int c4 = blockIdx.x * 256 + threadIdx.x;  // chunk of 4 columns
+__global__ __launch_bounds__(64) void lora_da_partial_kernel(const float* __restrict__ x, const float* __restrict__ dt,
+                                                             float* __restrict__ part, int rows, int width,
+                                                             unsigned seg_mask, float p, uint64_t seed,
+                                                             uint32_t stream_base, int rows_per_slice) {
+  const int c4 = blockIdx.x * 64 + threadIdx.x;  // chunk of 4 columns
   const int slice = blockIdx.y;
   if (c4 * 4 >= width) return;
   const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(256) void lora_da_partial_kernel(const float* __res
   for (int s = 0; s < NSEG; ++s)
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[s][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
   for (int m = m0; m < m1; ++m) {
     const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * width + 4 * c4);
     const float* dr = dt + (size_t)m * (NSEG * R);
@@ -177,14 +182,24 @@ __global__ __launch_bounds__(256) void lora_da_partial_kernel(const float* __res
       *reinterpret_cast<float4*>(part + ((size_t)slice * (NSEG * R) + s * R + j) * width + 4 * c4) = acc[s][j];
 }
 
-// out[i] += sum_slice part[slice][i]      (fixed order => bitwise reproducible)
-__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                            size_t n, int slices, float scale) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// out[i] += scale * sum_slice part[slice][i].  64 outputs x 16 slice groups per block; group g sums slices
+// g, g+16, ... and the 16 group sums are added in a fixed order => bitwise reproducible.
+__global__ __launch_bounds__(1024) void reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                             size_t n, int slices, float scale) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
   float acc = 0.f;
-  for (int s = 0; s < slices; ++s) acc += part[(size_t)s * n + i];
-  out[i] += scale * acc;
+  if (i < n)
+    for (int s = grp; s < slices; s += 16) acc += part[(size_t)s * n + i];
+  red[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    out[i] += scale * t;
+  }
 }
 
 // dx[m,k] += sum_{s,j} dt[m, s*r+j] * A[s*r+j, k] * dropscale_s(m,k)       one wave per row
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ 
   }
 }
 
-constexpr int LORA_SLICE_ROWS = 256;
+constexpr int LORA_SLICE_ROWS = 64;
 
 }  // namespace clipfs
 
@@ -261,7 +276,7 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
                       float scale, float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st) {
   const int slices = (rows + LORA_SLICE_ROWS - 1) / LORA_SLICE_ROWS;
   const int cols = nseg * segw;
-  hipLaunchKernelGGL(lora_dt_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dy, B, dt, rows, segw, R, nseg, seg_mask,
+  hipLaunchKernelGGL((lora_dt_kernel<R>), dim3((rows + 3) / 4), dim3(256), 0, st, dy, B, dt, rows, segw, nseg, seg_mask,
                      scale);
   CLIPFS_CHECK(launch_status());
   // dB
@@ -270,19 +285,19 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
                      rows, cols, segw, nseg, LORA_SLICE_ROWS);
   CLIPFS_CHECK(launch_status());
   const size_t nb = (size_t)cols * R;
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, part_b, dB, nb, slices,
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(1024), 0, st, part_b, dB, nb, slices,
                      scale);
   CLIPFS_CHECK(launch_status());
   // dA
   float* part_a = work + (size_t)slices * nb;
-  const dim3 ga((width / 4 + 255) / 256, slices);
+  const dim3 ga((width / 4 + 63) / 64, slices);
   switch (nseg) {
     case 1:
-      hipLaunchKernelGGL((lora_da_partial_kernel<R, 1>), ga, dim3(256), 0, st, x, dt, part_a, rows, width, seg_mask, p,
+      hipLaunchKernelGGL((lora_da_partial_kernel<R, 1>), ga, dim3(64), 0, st, x, dt, part_a, rows, width, seg_mask, p,
                          seed, stream_base, LORA_SLICE_ROWS);
       break;
     case 3:
-      hipLaunchKernelGGL((lora_da_partial_kernel<R, 3>), ga, dim3(256), 0, st, x, dt, part_a, rows, width, seg_mask, p,
+      hipLaunchKernelGGL((lora_da_partial_kernel<R, 3>), ga, dim3(64), 0, st, x, dt, part_a, rows, width, seg_mask, p,
                          seed, stream_base, LORA_SLICE_ROWS);
       break;
     default:
@@ -291,7 +306,7 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
   }
   CLIPFS_CHECK(launch_status());
   const size_t na = (size_t)nseg * R * width;
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, part_a, dA, na, slices,
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((na + 63) / 64)), dim3(1024), 0, st, part_a, dA, na, slices,
                      1.0f);
   CLIPFS_CHECK(launch_status());
   if (dx) {
