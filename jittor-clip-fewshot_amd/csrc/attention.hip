@@ -1,55 +1,100 @@
-// Self-attention forward / backward for head_dim 64 and short sequences (L <= 128: CLIP
-// ViT-B/32 L = 50 or 54 with VPT, text L = 77), one workgroup (4 waves) per (batch, head).
+// Self-attention forward / backward for head_dim 64 and short sequences (CLIP ViT-B/32: L = 50, 54 with
+// VPT; text: L = 77), one workgroup (4 waves) per (batch, head).
 //
-// This is ~1 % of the layer's FLOPs (2*2*L^2*64 per head vs 24*L*d^2 per image for the GEMMs) and
-// the fp32 matrix rate equals the fp32 vector rate on gfx950, so it runs on the VALU:
-//   * scores: key-per-lane.  Lane j keeps K[j][0:64] in 64 VGPRs (second set for L > 64); the
-//     query row is read from LDS as a broadcast; s_ij never leaves registers;
-//   * softmax: wave64 max / sum by cross-lane shuffles;
-//   * PV: lane = output column d; p_ij is broadcast with v_readlane, V[j][:] is an LDS row
-//     (conflict free).  Heads are merged by the store address (no permute pass).
-// The [L, L] score / probability matrix of the reference (jclip/mha.py:79-83, a round trip through
-// HBM of 30-77 MB per layer) stays in registers (forward) or LDS (backward).
+// ~1 % of the layer's FLOPs, and the fp32 matrix rate equals the fp32 vector rate on gfx950, so this runs on
+// the VALU -- what matters is operand delivery.  v1 read one LDS word per FMA (LDS-bound, 20 % VALU
+// utilisation); here every inner loop is  FMA(register operand, broadcast operand):
+//   * "row" operands (K rows, V rows: lane = key j) and "column" operands (V / K / Q / dO columns:
+//     lane = feature d) live in VGPRs, loaded once per wave;
+//   * the broadcast operand is either a wave-uniform global row (q_i, dO_i: scalar/broadcast loads) or a
+//     probability / score-gradient vector that the wave parked in LDS and reads back 4 at a time with one
+//     same-address ds_read_b128 (1 LDS instruction per 4 FMAs);
+//   * softmax max / sum are DPP wave reductions (common.h).
+// The [L, L] matrices of the reference (jclip/mha.py:79-83: a 30-77 MB HBM round trip per layer) stay on
+// chip: registers in the forward, LDS (P^T, dS^T, dS) in the backward.  Heads are merged by the store
+// address (no permute pass, mha.py:458).
 #include "common.h"
+
+#include <stdlib.h>
 
 namespace clipfs {
 
 constexpr int HD = 64;
+constexpr int KSTRIDE = 68;  // staged K/V row stride (floats): 16-byte aligned, conflict-free ds_read_b128 by row
 
-__device__ __forceinline__ float bcast_lane(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// cooperative copy of L rows of 64 floats (global row stride ld) into LDS rows of KSTRIDE floats
+__device__ __forceinline__ void stage_rows(const float* __restrict__ base, size_t ld, float* __restrict__ dst, int L,
+                                           int tid) {
+  for (int idx = tid; idx < L * (HD / 4); idx += (int)blockDim.x) {
+    const int r = idx >> 4, c = idx & 15;
+    *reinterpret_cast<f32x4*>(dst + r * KSTRIDE + 4 * c) = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + 4 * c);
+  }
 }
 
-// scores of query row `i` against this lane's keys (raw dot * scale, masked to -inf)
+// lane j takes row j (+64 per kk) of a staged [L][KSTRIDE] image into registers; rows >= L are zero
 template <int KPL>
-__device__ __forceinline__ void row_scores(const float* __restrict__ sQrow, const float (&kreg)[KPL][HD], int i,
-                                           int lane, int L, int causal, float (&s)[KPL]) {
-#pragma unroll
-  for (int kk = 0; kk < KPL; ++kk) s[kk] = 0.f;
-#pragma unroll
-  for (int c = 0; c < HD / 4; ++c) {
-    const float4 q = *reinterpret_cast<const float4*>(sQrow + 4 * c);
-#pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
-      s[kk] = fmaf(q.x, kreg[kk][4 * c + 0], s[kk]);
-      s[kk] = fmaf(q.y, kreg[kk][4 * c + 1], s[kk]);
-      s[kk] = fmaf(q.z, kreg[kk][4 * c + 2], s[kk]);
-      s[kk] = fmaf(q.w, kreg[kk][4 * c + 3], s[kk]);
-    }
-  }
+__device__ __forceinline__ void rows_to_regs(const float* __restrict__ s, int lane, int L, float (&reg)[KPL][HD]) {
 #pragma unroll
   for (int kk = 0; kk < KPL; ++kk) {
     const int j = lane + 64 * kk;
-    s[kk] *= 0.125f;  // 1/sqrt(64), applied after the dot product (mha.py:79)
-    if (j >= L || (causal && j > i)) s[kk] = -INFINITY;
+    const bool ok = j < L;
+    const float* row = s + (ok ? j : 0) * KSTRIDE;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * c);
+      reg[kk][4 * c + 0] = ok ? v[0] : 0.f;
+      reg[kk][4 * c + 1] = ok ? v[1] : 0.f;
+      reg[kk][4 * c + 2] = ok ? v[2] : 0.f;
+      reg[kk][4 * c + 3] = ok ? v[3] : 0.f;
+    }
   }
 }
 
-template <int KPL>
-__device__ __forceinline__ void row_softmax(float (&s)[KPL]) {
-  float m = s[0];
+// lane d takes column d of L global rows (coalesced 256-byte row reads); entries >= L are zero
+template <int LMAX>
+__device__ __forceinline__ void col_to_regs(const float* __restrict__ base, size_t ld, int lane, int L,
+                                            float (&reg)[LMAX]) {
+  // unconditional (row-clamped) loads so all of them are in flight together; zero-select afterwards
 #pragma unroll
-  for (int kk = 1; kk < KPL; ++kk) m = fmaxf(m, s[kk]);
+  for (int j = 0; j < LMAX; ++j) reg[j] = base[(size_t)min(j, L - 1) * ld + lane];
+#pragma unroll
+  for (int j = 0; j < LMAX; ++j) reg[j] = j < L ? reg[j] : 0.f;
+}
+
+// dot of the wave-uniform global row `u` (64 floats) with each of this lane's register rows
+template <int KPL>
+__device__ __forceinline__ void dot_rows(const float* __restrict__ u, const float (&reg)[KPL][HD], float (&out)[KPL]) {
+  float a0[KPL], a1[KPL];
+#pragma unroll
+  for (int kk = 0; kk < KPL; ++kk) a0[kk] = a1[kk] = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(u + 4 * c);  // same address in every lane
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+      a0[kk] = fmaf(q[0], reg[kk][4 * c + 0], a0[kk]);
+      a1[kk] = fmaf(q[1], reg[kk][4 * c + 1], a1[kk]);
+      a0[kk] = fmaf(q[2], reg[kk][4 * c + 2], a0[kk]);
+      a1[kk] = fmaf(q[3], reg[kk][4 * c + 3], a1[kk]);
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < KPL; ++kk) out[kk] = a0[kk] + a1[kk];
+}
+
+// scores -> probabilities for query row i (lane = key): scale after the dot (mha.py:79), mask, softmax
+template <int KPL>
+__device__ __forceinline__ void softmax_row(float (&s)[KPL], int i, int lane, int L, int causal) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int kk = 0; kk < KPL; ++kk) {
+    const int j = lane + 64 * kk;
+    s[kk] *= 0.125f;
+    if (j >= L || (causal && j > i)) s[kk] = -INFINITY;
+    m = fmaxf(m, s[kk]);
+  }
   m = wave_max(m);
   float sum = 0.f;
 #pragma unroll
@@ -62,165 +107,208 @@ __device__ __forceinline__ void row_softmax(float (&s)[KPL]) {
   for (int kk = 0; kk < KPL; ++kk) s[kk] = s[kk] / sum;
 }
 
+// sum_j vec[j] * col[j] for j < n: vec = 16-byte aligned LDS vector read as same-address b128 broadcasts.
+// Guarded in groups of 16 (4 reads in flight per group); vec must be finite up to the group boundary and
+// col[j >= L] == 0, so the overhang contributes exact zeros.
+template <int LMAX>
+__device__ __forceinline__ float bcast_dot(const float* __restrict__ vec, const float (&col)[LMAX], int n) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int g = 0; g < LMAX / 16; ++g) {
+    if (16 * g < n) {
+      f32x4 p[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) p[t] = *reinterpret_cast<const f32x4*>(vec + 16 * g + 4 * t);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a0 = fmaf(p[t][0], col[16 * g + 4 * t + 0], a0);
+        a1 = fmaf(p[t][1], col[16 * g + 4 * t + 1], a1);
+        a2 = fmaf(p[t][2], col[16 * g + 4 * t + 2], a2);
+        a3 = fmaf(p[t][3], col[16 * g + 4 * t + 3], a3);
+      }
+    }
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+// two query rows (uniform global rows u0, u1) against this lane's K rows read from the staged LDS image:
+// each ds_read_b128 of K feeds 8 FMAs (used when the K rows do not fit in VGPRs next to the V column)
 template <int KPL>
-__device__ __forceinline__ void load_rows_to_regs(const float* __restrict__ base, size_t row_stride, int lane, int L,
-                                                  float (&reg)[KPL][HD]) {
+__device__ __forceinline__ void dot_rows_lds2(const float* __restrict__ u0, const float* __restrict__ u1,
+                                              const float* __restrict__ sK, int lane, int L, float (&o0)[KPL],
+                                              float (&o1)[KPL]) {
+  const float* row[KPL];
 #pragma unroll
   for (int kk = 0; kk < KPL; ++kk) {
     const int j = lane + 64 * kk;
-    if (j < L) {
-      const float4* src = reinterpret_cast<const float4*>(base + (size_t)j * row_stride);
+    row[kk] = sK + (j < L ? j : 0) * KSTRIDE;  // rows >= L are masked to -inf afterwards
+    o0[kk] = o1[kk] = 0.f;
+  }
 #pragma unroll
-      for (int c = 0; c < HD / 4; ++c) {
-        const float4 v = src[c];
-        reg[kk][4 * c + 0] = v.x;
-        reg[kk][4 * c + 1] = v.y;
-        reg[kk][4 * c + 2] = v.z;
-        reg[kk][4 * c + 3] = v.w;
+  for (int c = 0; c < HD / 4; ++c) {
+    const f32x4 qa = *reinterpret_cast<const f32x4*>(u0 + 4 * c);
+    const f32x4 qb = *reinterpret_cast<const f32x4*>(u1 + 4 * c);
+#pragma unroll
+    for (int kk = 0; kk < KPL; ++kk) {
+      const f32x4 k = *reinterpret_cast<const f32x4*>(row[kk] + 4 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[kk] = fmaf(qa[e], k[e], o0[kk]);
+        o1[kk] = fmaf(qb[e], k[e], o1[kk]);
       }
-    } else {
-#pragma unroll
-      for (int c = 0; c < HD; ++c) reg[kk][c] = 0.f;
     }
   }
 }
 
-__device__ __forceinline__ void stage_rows(const float* __restrict__ base, size_t row_stride, float* __restrict__ dst,
-                                           int L, int tid) {
-  for (int idx = tid; idx < L * (HD / 4); idx += 256) {
-    const int r = idx >> 4, c = idx & 15;
-    *reinterpret_cast<float4*>(dst + r * HD + 4 * c) =
-        *reinterpret_cast<const float4*>(base + (size_t)r * row_stride + 4 * c);
-  }
-}
-
-template <int KPL>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <int LMAX>
+__global__ __launch_bounds__(512) void attention_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             int L, int H, int causal) {
+  constexpr int KPL = (LMAX + 63) / 64;
+  constexpr int PROW = 64 * KPL;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sQ = smem;           // [L][64]
-  float* sV = smem + L * HD;  // [L][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sK = smem;                 // [L][KSTRIDE] staged K rows
+  float* sP = smem + L * KSTRIDE;   // [16][PROW] probability rows of the waves' current queries
+  const int NW = (int)blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int d = H * HD;
   const size_t ld = (size_t)3 * d;
   const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
-  stage_rows(q0, ld, sQ, L, tid);
-  stage_rows(q0 + 2 * d, ld, sV, L, tid);
-  float kreg[KPL][HD];
-  load_rows_to_regs<KPL>(q0 + d, ld, lane, L, kreg);
+  float* o0 = out + (size_t)b * L * d + (size_t)h * HD;
+  stage_rows(q0 + d, ld, sK, L, tid);
+  float vcol[LMAX];
+  col_to_regs<LMAX>(q0 + 2 * d, ld, lane, L, vcol);  // V[:, lane]
   __syncthreads();
-  for (int i = wave; i < L; i += 4) {
-    float s[KPL];
-    row_scores<KPL>(sQ + i * HD, kreg, i, lane, L, causal, s);
-    row_softmax<KPL>(s);
-    const int jmax = causal ? i + 1 : L;
-    float o = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
-      const int jend = min(jmax - 64 * kk, 64);
-      for (int j = 0; j < jend; ++j) o = fmaf(bcast_lane(s[kk], j), sV[(j + 64 * kk) * HD + lane], o);
+  if constexpr (KPL == 1) {
+    float krow[KPL][HD];
+    rows_to_regs<KPL>(sK, lane, L, krow);
+    float* myP = sP + wave * PROW;
+    for (int i = wave; i < L; i += NW) {
+      float s[KPL];
+      dot_rows<KPL>(q0 + (size_t)i * ld, krow, s);
+      softmax_row<KPL>(s, i, lane, L, causal);
+      myP[lane] = s[0];
+      __builtin_amdgcn_wave_barrier();  // same wave writes then reads: LDS is in order per wave
+      const float o = bcast_dot<LMAX>(myP, vcol, causal ? i + 1 : L);
+      __builtin_amdgcn_wave_barrier();
+      o0[(size_t)i * d + lane] = o;
     }
-    out[((size_t)b * L + i) * d + h * HD + lane] = o;
+  } else {
+    float* pa = sP + (2 * wave) * PROW;
+    float* pb = pa + PROW;
+    for (int i = wave; i < L; i += 2 * NW) {
+      const int i2 = i + NW;
+      const bool two = i2 < L;
+      float sa[KPL], sb[KPL];
+      dot_rows_lds2<KPL>(q0 + (size_t)i * ld, q0 + (size_t)(two ? i2 : i) * ld, sK, lane, L, sa, sb);
+      softmax_row<KPL>(sa, i, lane, L, causal);
+      softmax_row<KPL>(sb, two ? i2 : i, lane, L, causal);
+#pragma unroll
+      for (int kk = 0; kk < KPL; ++kk) {
+        pa[lane + 64 * kk] = sa[kk];
+        pb[lane + 64 * kk] = sb[kk];
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float oa = bcast_dot<LMAX>(pa, vcol, causal ? i + 1 : L);
+      const float ob = bcast_dot<LMAX>(pb, vcol, causal ? (two ? i2 : i) + 1 : L);
+      __builtin_amdgcn_wave_barrier();
+      o0[(size_t)i * d + lane] = oa;
+      if (two) o0[(size_t)i2 * d + lane] = ob;
+    }
   }
 }
 
-// Backward: dQ = scale * dS K, dK = scale * dS^T Q, dV = P^T dO with dS = P * (dP - rowsum(P*dP)),
-// dP = dO V^T.  P is recomputed (pass 1), never stored in HBM.
-template <int KPL>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ qkv,
+// Backward: dQ = scale dS K, dK = scale dS^T Q, dV = P^T dO, dS = P * (dP - rowsum(P * dP)), dP = dO V^T.
+// P is recomputed (phase A1), never stored in HBM.  Phases (register sets are reused between phases):
+//   A1  lane = key, K rows in VGPRs : P_i  -> LDS P^T[j][i]
+//   A2  lane = key, V rows in VGPRs : dP_i, dS_i -> LDS dS^T[j][i] and dS[i][j]   (scale folded into dS)
+//   C1  lane = d, dO and Q columns in VGPRs, per key j : dV[j], dK[j]  (P^T[j][:], dS^T[j][:] broadcast)
+//   C2  lane = d, K column in VGPRs, per query i      : dQ[i]         (dS[i][:] broadcast)
+template <int LMAX>
+__global__ __launch_bounds__(512) void attention_bwd_kernel(const float* __restrict__ qkv,
                                                             const float* __restrict__ dout,
-                                                            float* __restrict__ dqkv, int L, int H, int causal) {
+                                                            float* __restrict__ dqkv, int L, int H, int causal, int LP) {
+  constexpr int KPL = (LMAX + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LP = L + 1;  // padded row of the [L][L] matrices: column reads are conflict free
-  float* sQ = smem;
-  float* sK = sQ + L * HD;
-  float* sdO = sK + L * HD;
-  float* sP = sdO + L * HD;  // [L][LP]
-  float* sdS = sP + L * LP;  // [L][LP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sPT = smem;              // [L][LP]  P^T
+  float* sdST = sPT + L * LP;     // [L][LP]  dS^T
+  float* sdS = sdST + L * LP;     // [L][LP]  dS   (aliases the staging buffer below: LP >= KSTRIDE is not needed,
+  float* sKV = sdS;               //  [L][KSTRIDE] staged K rows, then V rows -- dead before dS is written)
+  const int NW = (int)blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int d = H * HD;
   const size_t ld = (size_t)3 * d;
   const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
   const float* do0 = dout + (size_t)b * L * d + (size_t)h * HD;
   float* dq0 = dqkv + (size_t)b * L * ld + (size_t)h * HD;
-  stage_rows(q0, ld, sQ, L, tid);
-  stage_rows(q0 + d, ld, sK, L, tid);
-  stage_rows(do0, (size_t)d, sdO, L, tid);
-  float reg[KPL][HD];
-  load_rows_to_regs<KPL>(q0 + d, ld, lane, L, reg);  // K rows
+  for (int idx = tid; idx < 2 * L * LP; idx += (int)blockDim.x) smem[idx] = 0.f;  // P^T, dS^T: finite zero padding
+  stage_rows(q0 + d, ld, sKV, L, tid);
   __syncthreads();
-  // pass 1: probabilities
-  for (int i = wave; i < L; i += 4) {
-    float s[KPL];
-    row_scores<KPL>(sQ + i * HD, reg, i, lane, L, causal, s);
-    row_softmax<KPL>(s);
-#pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
-      const int j = lane + 64 * kk;
-      if (j < L) sP[i * LP + j] = s[kk];
-    }
-  }
-  load_rows_to_regs<KPL>(q0 + 2 * d, ld, lane, L, reg);  // V rows replace K rows
-  __syncthreads();
-  // pass 2: dP, dS (kept in LDS for dK) and dQ rows
-  for (int i = wave; i < L; i += 4) {
-    float dp[KPL], pv[KPL];
-#pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) dp[kk] = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD / 4; ++c) {
-      const float4 g = *reinterpret_cast<const float4*>(sdO + i * HD + 4 * c);
+  {
+    float rows[KPL][HD];
+    rows_to_regs<KPL>(sKV, lane, L, rows);  // K rows
+    __syncthreads();
+    stage_rows(q0 + 2 * d, ld, sKV, L, tid);  // V rows replace K rows in the staging buffer
+    // A1: probabilities
+    for (int i = wave; i < L; i += NW) {
+      float s[KPL];
+      dot_rows<KPL>(q0 + (size_t)i * ld, rows, s);
+      softmax_row<KPL>(s, i, lane, L, causal);
 #pragma unroll
       for (int kk = 0; kk < KPL; ++kk) {
-        dp[kk] = fmaf(g.x, reg[kk][4 * c + 0], dp[kk]);
-        dp[kk] = fmaf(g.y, reg[kk][4 * c + 1], dp[kk]);
-        dp[kk] = fmaf(g.z, reg[kk][4 * c + 2], dp[kk]);
-        dp[kk] = fmaf(g.w, reg[kk][4 * c + 3], dp[kk]);
+        const int j = lane + 64 * kk;
+        if (j < L) sPT[j * LP + i] = s[kk];
       }
     }
-    float rs = 0.f;
+    __syncthreads();
+    rows_to_regs<KPL>(sKV, lane, L, rows);  // V rows
+    __syncthreads();                         // staging buffer is dead from here: it becomes dS
+    for (int idx = tid; idx < L * LP; idx += (int)blockDim.x) sdS[idx] = 0.f;
+    __syncthreads();
+    // A2: dP, dS
+    for (int i = wave; i < L; i += NW) {
+      float dp[KPL], pv[KPL];
+      dot_rows<KPL>(do0 + (size_t)i * d, rows, dp);
+      float rs = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
-      const int j = lane + 64 * kk;
-      pv[kk] = j < L ? sP[i * LP + j] : 0.f;
-      rs = fmaf(pv[kk], dp[kk], rs);
-    }
-    rs = wave_sum(rs);
-    float ds[KPL];
+      for (int kk = 0; kk < KPL; ++kk) {
+        const int j = lane + 64 * kk;
+        pv[kk] = j < L ? sPT[j * LP + i] : 0.f;
+        rs = fmaf(pv[kk], dp[kk], rs);
+      }
+      rs = wave_sum(rs);
 #pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
-      const int j = lane + 64 * kk;
-      ds[kk] = pv[kk] * (dp[kk] - rs) * 0.125f;
-      if (j < L) sdS[i * LP + j] = ds[kk];
+      for (int kk = 0; kk < KPL; ++kk) {
+        const int j = lane + 64 * kk;
+        const float ds = pv[kk] * (dp[kk] - rs) * 0.125f;
+        if (j < L) {
+          sdST[j * LP + i] = ds;
+          sdS[i * LP + j] = ds;
+        }
+      }
     }
-    const int jmax = causal ? i + 1 : L;
-    float acc = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
-      const int jend = min(jmax - 64 * kk, 64);
-      for (int j = 0; j < jend; ++j) acc = fmaf(bcast_lane(ds[kk], j), sK[(j + 64 * kk) * HD + lane], acc);
-    }
-    dq0[(size_t)i * ld + lane] = acc;
   }
   __syncthreads();
-  // pass 3: per key j, dV[j] = sum_i P_ij dO_i and dK[j] = sum_i dS_ij Q_i  (lane = column)
-  for (int j = wave; j < L; j += 4) {
-    const int i0 = causal ? j : 0;  // P_ij = 0 for i < j under the causal mask
-    float av = 0.f, ak = 0.f;
-    for (int ib = i0 & ~63; ib < L; ib += 64) {
-      const int ii = ib + lane;
-      const float pcol = ii < L ? sP[ii * LP + j] : 0.f;   // lane ii holds P[ii][j]
-      const float dcol = ii < L ? sdS[ii * LP + j] : 0.f;  // and dS[ii][j]
-      const int lo = max(i0 - ib, 0), hi = min(L - ib, 64);
-      for (int t = lo; t < hi; ++t) {
-        av = fmaf(bcast_lane(pcol, t), sdO[(ib + t) * HD + lane], av);
-        ak = fmaf(bcast_lane(dcol, t), sQ[(ib + t) * HD + lane], ak);
-      }
+  {
+    // C1: dV[j] = sum_i P_ij dO_i , dK[j] = sum_i dS_ij Q_i
+    float doc[LMAX], qc[LMAX];
+    col_to_regs<LMAX>(do0, (size_t)d, lane, L, doc);
+    col_to_regs<LMAX>(q0, ld, lane, L, qc);
+    for (int j = wave; j < L; j += NW) {
+      const float av = bcast_dot<LMAX>(sPT + j * LP, doc, L);
+      const float ak = bcast_dot<LMAX>(sdST + j * LP, qc, L);
+      dq0[(size_t)j * ld + 2 * d + lane] = av;
+      dq0[(size_t)j * ld + d + lane] = ak;
     }
-    dq0[(size_t)j * ld + d + lane] = ak;
-    dq0[(size_t)j * ld + 2 * d + lane] = av;
+  }
+  {
+    // C2: dQ[i] = sum_j dS_ij K_j
+    float kc[LMAX];
+    col_to_regs<LMAX>(q0 + d, ld, lane, L, kc);
+    for (int i = wave; i < L; i += NW) dq0[(size_t)i * ld + lane] = bcast_dot<LMAX>(sdS + i * LP, kc, L);
   }
 }
 
@@ -228,6 +316,14 @@ static int check_attn(const char* what, int batch, int seq, int heads, int max_s
   CLIPFS_REQUIRE(batch > 0 && heads > 0 && seq > 0 && seq <= max_seq, "%s: batch %d seq %d heads %d unsupported (seq <= %d)",
                  what, batch, seq, heads, max_seq);
   return CLIPFS_OK;
+}
+
+// padded row length of the LDS [L][LP] matrices: >= L rounded up to 4 (b128 broadcast reads), LP / 4 odd so the
+// transposed (stride-LP) writes spread over 8 distinct bank groups
+static int padded_lp(int seq) {
+  int lp = (seq + 3) & ~3;
+  if (((lp >> 2) & 1) == 0) lp += 4;
+  return lp;
 }
 
 }  // namespace clipfs
@@ -238,42 +334,50 @@ extern "C" int clipfs_attention_fwd(const float* qkv, float* out, int batch, int
                                     void* stream) {
   CLIPFS_CHECK(check_attn("attention_fwd", batch, seq, heads, 128));
   CLIPFS_REQUIRE(qkv && out && aligned16(qkv), "attention_fwd: null or misaligned pointer");
-  const size_t lds = (size_t)2 * seq * HD * sizeof(float);
-  const dim3 grid(batch * heads), block(256);
+  static const int thr_cfg = getenv("CLIPFS_ATTN_FWD_THREADS") ? atoi(getenv("CLIPFS_ATTN_FWD_THREADS")) : 0;
+  const dim3 grid(batch * heads), block(thr_cfg ? thr_cfg : 256);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds1 = ((size_t)seq * KSTRIDE + 16 * 64) * sizeof(float);
+  const size_t lds2 = ((size_t)seq * KSTRIDE + 16 * 128) * sizeof(float);
   if (seq <= 64)
-    hipLaunchKernelGGL((attention_fwd_kernel<1>), grid, block, lds, (hipStream_t)stream, qkv, out, seq, heads, causal);
-  else {
-    static bool attr = false;
-    if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fwd_kernel<2>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * HD * 4);
-      attr = true;
-    }
-    hipLaunchKernelGGL((attention_fwd_kernel<2>), grid, block, lds, (hipStream_t)stream, qkv, out, seq, heads, causal);
-  }
+    hipLaunchKernelGGL((attention_fwd_kernel<64>), grid, block, lds1, st, qkv, out, seq, heads, causal);
+  else if (seq <= 80)
+    hipLaunchKernelGGL((attention_fwd_kernel<80>), grid, block, lds2, st, qkv, out, seq, heads, causal);
+  else if (seq <= 96)
+    hipLaunchKernelGGL((attention_fwd_kernel<96>), grid, block, lds2, st, qkv, out, seq, heads, causal);
+  else
+    hipLaunchKernelGGL((attention_fwd_kernel<128>), grid, block, lds2, st, qkv, out, seq, heads, causal);
   return launch_status();
 }
 
 extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, float* dqkv, int batch, int seq, int heads,
                                     int causal, void* stream) {
-  CLIPFS_CHECK(check_attn("attention_bwd", batch, seq, heads, 96));  // LDS: 3*L*64 + 2*L*(L+1) floats <= 160 KiB
+  // C1 keeps two columns of length LMAX in VGPRs: 2 * 96 is the most that fits without spilling
+  CLIPFS_CHECK(check_attn("attention_bwd", batch, seq, heads, 96));
   CLIPFS_REQUIRE(qkv && dout && dqkv && aligned16(qkv) && aligned16(dout), "attention_bwd: null or misaligned pointer");
-  const size_t lds = ((size_t)3 * seq * HD + (size_t)2 * seq * (seq + 1)) * sizeof(float);
-  const dim3 grid(batch * heads), block(256);
+  const int lp = padded_lp(seq);
+  // P^T, dS^T, and dS (whose storage first serves as the [seq][KSTRIDE] K/V staging buffer) + 16 floats overhang
+  const size_t third = (size_t)seq * (lp > KSTRIDE ? lp : KSTRIDE);
+  const size_t lds = ((size_t)2 * seq * lp + third + 16) * sizeof(float);
+  CLIPFS_REQUIRE(lds <= 160 * 1024, "attention_bwd: seq %d needs %zu bytes of LDS (> 160 KiB)", seq, lds);
+  static const int thr_cfg = getenv("CLIPFS_ATTN_BWD_THREADS") ? atoi(getenv("CLIPFS_ATTN_BWD_THREADS")) : 0;
+  const dim3 grid(batch * heads), block(thr_cfg ? thr_cfg : (seq > 64 ? 512 : 256));
+  hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {
-    const int maxlds = (3 * 96 * HD + 2 * 96 * 97) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<1>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<2>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<80>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<96>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   if (seq <= 64)
-    hipLaunchKernelGGL((attention_bwd_kernel<1>), grid, block, lds, (hipStream_t)stream, qkv, dout, dqkv, seq, heads,
-                       causal);
+    hipLaunchKernelGGL((attention_bwd_kernel<64>), grid, block, lds, st, qkv, dout, dqkv, seq, heads, causal, lp);
+  else if (seq <= 80)
+    hipLaunchKernelGGL((attention_bwd_kernel<80>), grid, block, lds, st, qkv, dout, dqkv, seq, heads, causal, lp);
   else
-    hipLaunchKernelGGL((attention_bwd_kernel<2>), grid, block, lds, (hipStream_t)stream, qkv, dout, dqkv, seq, heads,
-                       causal);
+    hipLaunchKernelGGL((attention_bwd_kernel<96>), grid, block, lds, st, qkv, dout, dqkv, seq, heads, causal, lp);
   return launch_status();
 }
