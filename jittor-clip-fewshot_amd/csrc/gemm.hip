@@ -35,6 +35,13 @@ struct GemmParams {
 
 constexpr int BK = 32;
 
+// 16-byte global -> LDS copy without a VGPR round trip (global_load_lds_dwordx4): the LDS destination is
+// wave-uniform base + lane * 16, the global source is per lane -- so the XOR swizzle goes on the SOURCE.
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // AMODE 0: dense A, K % 32 == 0 (the hot configuration: the K loop is pointer bumps + 16-byte loads only)
 // AMODE 1: patch im2col with patch == 32 (one K-step == one (channel, ky) image row segment)
 // AMODE 2: generic (dense with a K tail, or any patch size): per-element address arithmetic
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   for (int i = 0; i < A_CHUNKS; ++i) {
     const int row = (tid >> 3) + 32 * i;
     const int m = min(m0 + row, M - 1);
-    if (AMODE == 0 || (AMODE == 2 && g.a_mode == 0)) {
+    if (AMODE == 0 || AMODE == 3 || (AMODE == 2 && g.a_mode == 0)) {
       a_src[i] = g.A + (size_t)m * g.lda + (AMODE == 0 ? kc * 4 : 0);
     } else {
       const int b = m / p.patches, pp = m - b * p.patches;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
 
   f32x4 a_reg[A_CHUNKS], b_reg[B_CHUNKS];
   auto load_global = [&](int kt) __attribute__((always_inline)) {
-    if (AMODE == 0) {
+    if (AMODE == 0 || AMODE == 3) {
       const int k0 = kt * BK;
 #pragma unroll
       for (int i = 0; i < A_CHUNKS; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + k0);
@@ -151,6 +158,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     for (int i = 0; i < B_CHUNKS; ++i) *reinterpret_cast<f32x4*>(s + b_lds[i]) = b_reg[i];
   };
 
+  // ---- AMODE 3: dense operands copied global -> LDS directly (no VGPR staging, no ds_write) -------------
+  // one global_load_lds_dwordx4 covers 8 tile rows x 128 B = 1 KiB of the LDS image (lane l: row l / 8,
+  // slot l % 8); wave w owns row groups w, w + 4, ...; the swizzle is applied to the per-lane SOURCE chunk.
+  const float* ga_src[A_CHUNKS];
+  const float* gb_src[B_CHUNKS];
+  int ga_lds[A_CHUNKS], gb_lds[B_CHUNKS];
+  if (AMODE == 3) {
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      const int r0 = 8 * (uw + 4 * i), r = r0 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      ga_src[i] = g.A + (size_t)min(m0 + r, M - 1) * g.lda + 4 * c;
+      ga_lds[i] = r0 * BK;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) {
+      const int r0 = 8 * (uw + 4 * i), r = r0 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      gb_src[i] = g.B + (size_t)min(n0 + r, N - 1) * g.ldb + 4 * c;
+      gb_lds[i] = BM * BK + r0 * BK;
+    }
+  }
+  auto glds_stage = [&](int kt, int stage) __attribute__((always_inline)) {
+    float* s = smem + stage * STAGE_FLOATS;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) glds16(ga_src[i] + k0, s + ga_lds[i]);
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) glds16(gb_src[i] + k0, s + gb_lds[i]);
+  };
+
   // ---- fragment read addresses -----------------------------------------------------------------
   const int fr = lane & 31, fh = lane >> 5;
   const int swz = (fr >> 1) & 7;  // (row >> 1) & 7 : tile bases are multiples of 32
@@ -192,6 +231,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
       }
     }
   };
+  if (AMODE == 3) {
+    glds_stage(0, 0);
+    __syncthreads();  // emits vmcnt(0) for the LDS-DMA in flight, then the barrier
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      glds_stage(kt + 1, (kt + 1) & 1);  // the other stage was last read before the previous barrier
+      compute(smem + (kt & 1) * STAGE_FLOATS);
+      __syncthreads();
+    }
+    compute(smem + ((nk - 1) & 1) * STAGE_FLOATS);
+  } else {
   // prologue, steady state (prefetch unconditionally: the staged registers must stay in VGPRs), tail
   load_global(0);
   store_lds(0);
@@ -204,6 +253,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     if (!(p.ablate & 4)) __syncthreads();
   }
   compute(smem + ((nk - 1) & 1) * STAGE_FLOATS);
+  }
 
   // ---- epilogue ------------------------------------------------------------------------------
   // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -362,7 +412,8 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
     return launch<128, 64, 0>(p, s);
   }
   p.n_blocks_n = (a.N + 127) / 128;
-  if (a.a_mode == 0 && (a.K % BK) == 0) return launch<64, 128, 0>(p, s);
+  static const int glds_cfg = getenv("CLIPFS_GEMM_GLDS") ? atoi(getenv("CLIPFS_GEMM_GLDS")) : 1;  // 0: register staging (A/B aid)
+  if (a.a_mode == 0 && (a.K % BK) == 0) return glds_cfg ? launch<64, 128, 3>(p, s) : launch<64, 128, 0>(p, s);
   if (a.a_mode == 1 && a.patch == 32 && (a.img_res & 3) == 0) return launch<64, 128, 1>(p, s);
   return launch<64, 128, 2>(p, s);
 }
