@@ -19,6 +19,8 @@ text tower is class-sharded (403/N captions per rank), collectives: all-gather +
 Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (dominant kernel = the fp32-MFMA GEMM; every
 GEMM launch of one extra, instrumented step is bracketed by HIP events on its launch stream) and
 ``cpu_baseline`` (the CPU oracle timed on the host cores on a bounded sample; N = 1 only).
+In the timed region the text tower runs on a side HIP stream next to the image tower (they are independent
+until the logits); the instrumented roofline step serialises them so each GEMM's duration is its own.
 """
 from __future__ import annotations
 
@@ -51,6 +53,8 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.25, help="LoRA input dropout (reference default 0.25)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial-towers", action="store_true",
+                    help="run the text and image towers back to back on one stream (default: text tower on a side stream)")
     ap.add_argument("--forward-only", action="store_true", help="time the zero-grad image forward only (diagnostic)")
     return ap.parse_args()
 
@@ -74,6 +78,7 @@ def build_trainer(dev, args, world):
     ctx = torch.nn.Parameter(model.token_embedding.weight.data[ids].clone())
     model.train()
     tr = L.LoRATrainer(model, prompt_ctx=ctx, shard_text=not args.no_shard_text)
+    tr.overlap_towers = not args.serial_towers
     return model, tr, cfg
 
 
@@ -189,10 +194,13 @@ def main():
     roof = None
     if not args.no_roofline:
         lib = _lib.load()
+        overlap = tr.overlap_towers
+        tr.overlap_towers = False  # per-kernel durations are only meaningful when nothing else shares the GPU
         lib.clipfs_gemm_timing(1)
         step()
         torch.cuda.synchronize()
         lib.clipfs_gemm_timing(0)
+        tr.overlap_towers = overlap
         tms, tfl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
         lib.clipfs_gemm_timing_collect(ctypes.byref(tms), ctypes.byref(tfl), ctypes.byref(n))
         if n.value > 0 and tms.value > 0:
@@ -221,7 +229,7 @@ def main():
                                    "fwd+bwd on 403 captions + image tower fwd+bwd + 100*cos CE + AdamW"
                        if not args.forward_only else "ViT-B/32 image tower forward only (diagnostic)",
                        "global_batch": gb, "images_per_rank": n_img_local, "captions": args.classes,
-                       "lora_dropout": args.dropout, "parallelism": f"dp{world}" + ("" if args.no_shard_text or world == 1 else "+class-sharded-text")},
+                       "lora_dropout": args.dropout, "tower_streams": 1 if args.serial_towers else 2, "parallelism": f"dp{world}" + ("" if args.no_shard_text or world == 1 else "+class-sharded-text")},
             "algorithmic_tflop_per_step": round(step_tflop, 3),
             "step_tflops": round(step_tflop / (ms * 1e-3), 2),
             "step_frac_of_fp32_mfma_peak": round(step_tflop / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * world), 4),

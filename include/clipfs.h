@@ -75,8 +75,16 @@ typedef struct clipfs_gemm_args {
   float lora_scale;
   int a_mode;              /* 0 dense, 1 patch im2col */
   int img_res, patch, out_tokens; /* a_mode 1 */
+  float* workspace;        /* optional split-K scratch (NULL: never split); see clipfs_gemm_workspace_floats */
+  size_t workspace_floats;
 } clipfs_gemm_args;
 int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
+/* Products with few output tiles (small per-rank batches) are cut along K into `clipfs_gemm_splits` slices
+ * whose raw partial sums go to `workspace` and are combined, in slice order, by a second kernel that applies
+ * the epilogue -- deterministic, no float atomics.  workspace_floats >= clipfs_gemm_workspace_floats(M,N,K)
+ * enables it; 0 is returned for shapes that are never split. */
+int clipfs_gemm_splits(int M, int N, int K);
+size_t clipfs_gemm_workspace_floats(int M, int N, int K);
 /* Diagnostics for bench.py's roofline leg (never enabled inside a timed region): while enabled, every
  * GEMM launch of the calling thread is bracketed by HIP events on its launch stream;
  * clipfs_gemm_timing_collect synchronises on them and returns the summed kernel time, the summed

@@ -32,6 +32,7 @@ class GemmArgs(C.Structure):
         ("lora_r", C.c_int), ("lora_nseg", C.c_int), ("lora_seg_width", C.c_int),
         ("lora_scale", C.c_float),
         ("a_mode", C.c_int), ("img_res", C.c_int), ("patch", C.c_int), ("out_tokens", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t),
     ]
 
 
@@ -64,6 +65,8 @@ SIGNATURES = {
     "clipfs_abi_version": (_i, []),
     "clipfs_last_error": (C.c_char_p, []),
     "clipfs_gemm_nt": (_i, [C.POINTER(GemmArgs), _p]),
+    "clipfs_gemm_splits": (_i, [_i, _i, _i]),
+    "clipfs_gemm_workspace_floats": (_sz, [_i, _i, _i]),
     "clipfs_gemm_timing": (_i, [_i]),
     "clipfs_gemm_timing_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "clipfs_layernorm_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p]),

@@ -30,7 +30,7 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
             act: int = 0, aux_out=None, aux_in=None, alpha: float = 1.0, lora_t=None, lora_b=None,
-            lora_seg_width: int = 0, lora_scale: float = 0.0) -> torch.Tensor:
+            lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True) -> torch.Tensor:
     """out = epi(alpha * a @ b.T); a [M,K], b [N,K]."""
     _f32(a), _f32(b)
     M, K = a.shape
@@ -56,7 +56,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         g.lora_nseg = lora_t.shape[1] // r
         g.lora_seg_width = lora_seg_width or N
         g.lora_scale = lora_scale
-    check(_lib.load().clipfs_gemm_nt(C.byref(g), _stream()), "gemm_nt")
+    lib = _lib.load()
+    ws = None
+    nws = lib.clipfs_gemm_workspace_floats(M, N, K) if split_k else 0
+    if nws:
+        ws = torch.empty(nws, device=a.device, dtype=torch.float32)
+        g.workspace, g.workspace_floats = _p(ws), nws
+    check(lib.clipfs_gemm_nt(C.byref(g), _stream()), "gemm_nt")
     return out
 
 

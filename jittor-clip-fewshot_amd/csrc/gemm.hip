@@ -30,10 +30,40 @@ struct GemmParams {
   int n_blocks_n;  // number of BN-wide column blocks
   int patches;     // a_mode 1: patches per image (G*G)
   int grid_g;      // a_mode 1: patches per side
+  int splits;      // split-K factor (1 = none): unit u = tile * splits + split, split s covers K-steps [s*nk/S, (s+1)*nk/S)
+  float* part;     // splits > 1: raw partial sums, slab s at part + s * M * N (row-major, ld = N)
   int ablate;      // tuning aid (CLIPFS_GEMM_ABLATE): 1 no global prefetch, 2 no LDS store, 4 no barrier -- WRONG RESULTS
 };
 
 constexpr int BK = 32;
+
+// The fused epilogue for one output element (order documented in include/clipfs.h); used by the GEMM
+// kernel and by the split-K combine kernel.
+__device__ __forceinline__ void epilogue_store(const clipfs_gemm_args& g, int patches, int m, int n, float accv) {
+  float v = g.alpha * accv + (g.bias ? g.bias[n] : 0.f);
+  if (g.lora_t) {
+    const int lseg = n / g.lora_seg_width;
+    const float* lb = g.lora_b + (size_t)n * g.lora_r;
+    const float* t = g.lora_t + (size_t)m * (g.lora_nseg * g.lora_r) + lseg * g.lora_r;
+    float d = 0.f;
+    for (int jj = 0; jj < g.lora_r; ++jj) d = fmaf(t[jj], lb[jj], d);
+    v = fmaf(g.lora_scale, d, v);
+  }
+  size_t orow = (size_t)m, rrow = (size_t)m;
+  if (g.a_mode == 1) {
+    const int b = m / patches, pp = m - b * patches;
+    orow = (size_t)b * g.out_tokens + 1 + pp;
+    rrow = (size_t)(1 + pp);
+  }
+  if (g.act == 1) {
+    if (g.aux_out) g.aux_out[orow * g.ldc + n] = v;
+    v = quick_gelu(v);
+  } else if (g.act == 2) {
+    v *= quick_gelu_grad(g.aux_in[orow * g.ldc + n]);
+  }
+  if (g.residual) v += g.residual[rrow * g.ldres + n];
+  g.C[orow * g.ldc + n] = v;
+}
 
 // 16-byte global -> LDS copy without a VGPR round trip (global_load_lds_dwordx4): the LDS destination is
 // wave-uniform base + lane * 16, the global source is per lane -- so the XOR swizzle goes on the SOURCE.
@@ -48,8 +78,10 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
 template <int BM, int BN, int AMODE>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int TM = BM / 64;            // 32x32 tiles per wave along M
-  constexpr int TN = BN / 64;            // ... along N
+  constexpr int WM = BM >= 64 ? 2 : 1;   // wave grid WM x WN (4 waves); BM = 32 puts the 4 waves side by side
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);     // 32x32 tiles per wave along M
+  constexpr int TN = BN / (32 * WN);     // ... along N
   constexpr int A_CHUNKS = BM * 8 / 256; // 16-byte chunks staged per thread
   constexpr int B_CHUNKS = BN * 8 / 256;
   constexpr int STAGE_FLOATS = (BM + BN) * BK;
@@ -58,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD, speed only),
   // each XCD has a private 4 MB L2: give every XCD a CONTIGUOUS run of the tile list, and order the list in
   // super-tiles of GM m-blocks x all n-blocks (m fastest) so the ~96 tiles an XCD runs at once share
@@ -69,6 +101,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     const int xcd = bid & 7, li = bid >> 3, q = nwg >> 3, r = nwg & 7;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + li;
   }
+  const int split = tile % p.splits;  // consecutive units = the K slices of one tile (same XCD: shared panels)
+  tile /= p.splits;
   constexpr int GM = 16;
   const int nbn = p.n_blocks_n;
   const int grp = tile / (GM * nbn);
@@ -195,9 +229,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   const int swz = (fr >> 1) & 7;  // (row >> 1) & 7 : tile bases are multiples of 32
   int a_frag[TM], b_frag[TN];
 #pragma unroll
-  for (int t = 0; t < TM; ++t) a_frag[t] = (wm * (BM / 2) + t * 32 + fr) * BK;
+  for (int t = 0; t < TM; ++t) a_frag[t] = (wm * (BM / WM) + t * 32 + fr) * BK;
 #pragma unroll
-  for (int t = 0; t < TN; ++t) b_frag[t] = BM * BK + (wn * (BN / 2) + t * 32 + fr) * BK;
+  for (int t = 0; t < TN; ++t) b_frag[t] = BM * BK + (wn * (BN / WN) + t * 32 + fr) * BK;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -207,7 +241,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk_all = (K + BK - 1) / BK;
+  const int kt0 = (int)((long)split * nk_all / p.splits);
+  const int nk = (int)((long)(split + 1) * nk_all / p.splits) - kt0;  // K-steps of this unit (>= 1: host guarantees)
   auto compute = [&](const float* s) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -232,21 +268,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     }
   };
   if (AMODE == 3) {
-    glds_stage(0, 0);
+    glds_stage(kt0, 0);
     __syncthreads();  // emits vmcnt(0) for the LDS-DMA in flight, then the barrier
     for (int kt = 0; kt + 1 < nk; ++kt) {
-      glds_stage(kt + 1, (kt + 1) & 1);  // the other stage was last read before the previous barrier
+      glds_stage(kt0 + kt + 1, (kt + 1) & 1);  // the other stage was last read before the previous barrier
       compute(smem + (kt & 1) * STAGE_FLOATS);
       __syncthreads();
     }
     compute(smem + ((nk - 1) & 1) * STAGE_FLOATS);
   } else {
   // prologue, steady state (prefetch unconditionally: the staged registers must stay in VGPRs), tail
-  load_global(0);
+  load_global(kt0);
   store_lds(0);
   __syncthreads();
   for (int kt = 0; kt + 1 < nk; ++kt) {
-    if (!(p.ablate & 1)) load_global(kt + 1);  // global -> registers, one K-step ahead
+    if (!(p.ablate & 1)) load_global(kt0 + kt + 1);  // global -> registers, one K-step ahead
     __builtin_amdgcn_sched_barrier(0);         // keep the loads ABOVE the MFMAs (hipcc sinks them to the ds_write otherwise)
     compute(smem + (kt & 1) * STAGE_FLOATS);   // 32 MFMAs per wave hide the load latency
     if (!(p.ablate & 2)) store_lds((kt + 1) & 1);  // registers -> the other LDS stage
@@ -259,46 +295,31 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / 2) + j * 32 + fr;
-    const bool n_ok = n < N;
-    const int nc = n_ok ? n : N - 1;
-    const float bias = g.bias ? g.bias[nc] : 0.f;
-    const float* lb = nullptr;
-    int lseg = 0;
-    if (g.lora_t) {
-      lseg = nc / g.lora_seg_width;
-      lb = g.lora_b + (size_t)nc * g.lora_r;
-    }
+    const int n = n0 + wn * (BN / WN) + j * 32 + fr;
+    if (n >= N) continue;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m >= M || !n_ok) continue;
-        float v = g.alpha * acc[i][j][r] + bias;
-        if (lb) {
-          const float* t = g.lora_t + (size_t)m * (g.lora_nseg * g.lora_r) + lseg * g.lora_r;
-          float d = 0.f;
-          for (int jj = 0; jj < g.lora_r; ++jj) d = fmaf(t[jj], lb[jj], d);
-          v = fmaf(g.lora_scale, d, v);
-        }
-        size_t orow = (size_t)m;
-        size_t rrow = (size_t)m;
-        if (g.a_mode == 1) {
-          const int b = m / p.patches, pp = m - b * p.patches;
-          orow = (size_t)b * g.out_tokens + 1 + pp;
-          rrow = (size_t)(1 + pp);
-        }
-        if (g.act == 1) {
-          if (g.aux_out) g.aux_out[orow * g.ldc + n] = v;
-          v = quick_gelu(v);
-        } else if (g.act == 2) {
-          v *= quick_gelu_grad(g.aux_in[orow * g.ldc + n]);
-        }
-        if (g.residual) v += g.residual[rrow * g.ldres + n];
-        g.C[orow * g.ldc + n] = v;
+        const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m >= M) continue;
+        if (p.splits > 1)
+          p.part[((size_t)split * M + m) * N + n] = acc[i][j][r];  // raw partial sum; combined in fixed order
+        else
+          epilogue_store(g, p.patches, m, n, acc[i][j][r]);
       }
     }
+  }
+}
+
+// split-K combine: C = epilogue( sum_s part[s] ), slabs added in index order (bitwise reproducible)
+__global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(const GemmParams p) {
+  const clipfs_gemm_args& g = p.a;
+  const size_t total = (size_t)g.M * g.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float v = 0.f;
+    for (int s = 0; s < p.splits; ++s) v += p.part[(size_t)s * total + i];
+    epilogue_store(g, p.patches, (int)(i / g.N), (int)(i % g.N), v);
   }
 }
 
@@ -328,11 +349,17 @@ static int launch(const GemmParams& p, hipStream_t stream) {
     tl.flops = 2.0 * p.a.M * (double)p.a.N * p.a.K;
     (void)hipEventRecord(tl.start, stream);
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, AMODE>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, AMODE>), dim3(mb * p.n_blocks_n * p.splits), dim3(256), lds, stream, p);
   if (g_timing) {
     (void)hipEventRecord(tl.stop, stream);
     if (!g_timed) g_timed = new std::vector<TimedLaunch>();
     g_timed->push_back(tl);
+  }
+  CLIPFS_CHECK(launch_status());
+  if (p.splits > 1) {
+    const size_t total = (size_t)p.a.M * p.a.N;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(gemm_splitk_combine_kernel, dim3(blocks), dim3(256), 0, stream, p);
   }
   return launch_status();
 }
@@ -340,6 +367,29 @@ static int launch(const GemmParams& p, hipStream_t stream) {
 }  // namespace clipfs
 
 using namespace clipfs;
+
+// Tile height: 64 x 128 normally; 32 x 128 when that leaves fewer than two tiles per CU (small per-rank batches).
+static inline int gemm_bm(int M, int N) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
+  return tiles < 512 ? 32 : 64;
+}
+
+// Split-K factor for a [M,N,K] product: only when even the 32 x 128 tiling leaves the 256 CUs short of work
+// (strong-scaling per-rank batches) and K is long enough to cut; the slab combine costs one extra pass over
+// S * M * N floats, so it is kept to 2-3 slices.
+extern "C" int clipfs_gemm_splits(int M, int N, int K) {
+  const long tiles = (long)((M + gemm_bm(M, N) - 1) / gemm_bm(M, N)) * ((N + 127) / 128);
+  const int nk = (K + BK - 1) / BK;
+  if (tiles >= 384 || nk < 16) return 1;
+  int s = tiles < 200 ? 3 : 2;
+  while (s > 1 && nk / s < 8) --s;
+  return s;
+}
+
+extern "C" size_t clipfs_gemm_workspace_floats(int M, int N, int K) {
+  const int s = clipfs_gemm_splits(M, N, K);
+  return s > 1 ? (size_t)s * M * N : 0;
+}
 
 extern "C" int clipfs_gemm_timing(int enable) {
   g_timing = enable != 0;
@@ -400,6 +450,15 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
     CLIPFS_REQUIRE(a.lora_seg_width % 32 == 0 && a.lora_seg_width * a.lora_nseg >= a.N, "gemm: lora segment width must be a multiple of 32 and cover N");
   }
   hipStream_t s = (hipStream_t)stream;
+  p.splits = 1;
+  p.part = nullptr;
+  {
+    const int want = clipfs_gemm_splits(a.M, a.N, a.K);
+    if (want > 1 && a.workspace && a.workspace_floats >= (size_t)want * a.M * a.N) {
+      p.splits = want;
+      p.part = a.workspace;
+    }
+  }
   // 64x128 tiles keep the tile count a large multiple of the CU count at the path's shapes
   // (M = 12800: 200 x N/128 tiles), 128x128 is used when there are plenty of tiles anyway.
   static const int tile_cfg = getenv("CLIPFS_GEMM_TILE") ? atoi(getenv("CLIPFS_GEMM_TILE")) : 0;  // tuning aid
@@ -412,6 +471,7 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
     return launch<128, 64, 0>(p, s);
   }
   p.n_blocks_n = (a.N + 127) / 128;
+  if (gemm_bm(a.M, a.N) == 32 && a.a_mode == 0 && (a.K % BK) == 0) return launch<32, 128, 3>(p, s);
   static const int glds_cfg = getenv("CLIPFS_GEMM_GLDS") ? atoi(getenv("CLIPFS_GEMM_GLDS")) : 1;  // 0: register staging (A/B aid)
   if (a.a_mode == 0 && (a.K % BK) == 0) return glds_cfg ? launch<64, 128, 3>(p, s) : launch<64, 128, 0>(p, s);
   if (a.a_mode == 1 && a.patch == 32 && (a.img_res & 3) == 0) return launch<64, 128, 1>(p, s);

@@ -245,7 +245,13 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ 
   }
 }
 
-constexpr int LORA_SLICE_ROWS = 64;
+// rows per reduction slice: 64 for large row counts, smaller when there are few rows so that the partial
+// kernels still put >= ~1000 waves on the chip (per-rank batches of 32 images: M = 1600)
+static inline int lora_slice_rows(int rows) {
+  int r = 64;
+  while (r > 8 && (rows + r - 1) / r < 256) r >>= 1;
+  return r;
+}
 
 }  // namespace clipfs
 
@@ -264,7 +270,8 @@ extern "C" int clipfs_lora_down(const float* x, const float* A, float* t, int ro
 }
 
 extern "C" size_t clipfs_lora_bwd_work_floats(int rows, int width, int r, int nseg) {
-  const size_t slices = (size_t)(rows + LORA_SLICE_ROWS - 1) / LORA_SLICE_ROWS;
+  const int sr = lora_slice_rows(rows);
+  const size_t slices = (size_t)(rows + sr - 1) / sr;
   // dB partials: slices * (nseg*segw) * r with segw <= 4*width (MLP never adapted; q/k/v/o segw == width)
   // dA partials: slices * nseg * r * width
   return slices * (size_t)nseg * r * width * 2 + 64;
@@ -274,7 +281,8 @@ template <int R>
 static int lora_bwd_r(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
                       float* dA, float* dB, float* dx, int rows, int width, int segw, int nseg, unsigned seg_mask,
                       float scale, float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st) {
-  const int slices = (rows + LORA_SLICE_ROWS - 1) / LORA_SLICE_ROWS;
+  const int sr = lora_slice_rows(rows);
+  const int slices = (rows + sr - 1) / sr;
   const int cols = nseg * segw;
   hipLaunchKernelGGL((lora_dt_kernel<R>), dim3((rows + 3) / 4), dim3(256), 0, st, dy, B, dt, rows, segw, nseg, seg_mask,
                      scale);
@@ -282,7 +290,7 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
   // dB
   float* part_b = work;
   hipLaunchKernelGGL((lora_db_partial_kernel<R>), dim3((cols + 255) / 256, slices), dim3(256), 0, st, dy, t, part_b,
-                     rows, cols, segw, nseg, LORA_SLICE_ROWS);
+                     rows, cols, segw, nseg, sr);
   CLIPFS_CHECK(launch_status());
   const size_t nb = (size_t)cols * R;
   hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(1024), 0, st, part_b, dB, nb, slices,
@@ -294,11 +302,11 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
   switch (nseg) {
     case 1:
       hipLaunchKernelGGL((lora_da_partial_kernel<R, 1>), ga, dim3(64), 0, st, x, dt, part_a, rows, width, seg_mask, p,
-                         seed, stream_base, LORA_SLICE_ROWS);
+                         seed, stream_base, sr);
       break;
     case 3:
       hipLaunchKernelGGL((lora_da_partial_kernel<R, 3>), ga, dim3(64), 0, st, x, dt, part_a, rows, width, seg_mask, p,
-                         seed, stream_base, LORA_SLICE_ROWS);
+                         seed, stream_base, sr);
       break;
     default:
       set_error("lora_bwd: nseg %d unsupported (1 or 3)", nseg);

@@ -35,7 +35,7 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
 }
 
 struct ScratchLayout {
-  size_t h, big, b3, b1, dt, work, total;
+  size_t h, big, b3, b1, dt, work, gemm_ws, gemm_ws_floats, total;
 };
 
 static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
@@ -48,6 +48,15 @@ static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
   S.b1 = o;   o += al4(M * d);
   S.dt = o;   o += al4(M * 4 * r);
   S.work = o; o += r ? al4(clipfs_lora_bwd_work_floats((int)M, (int)d, (int)r, 3)) : 0;
+  // split-K scratch for the largest of the tower's GEMM shapes (0 unless the row count is small)
+  size_t ws = 0;
+  const int shapes[7][2] = {{3 * (int)d, (int)d}, {(int)d, (int)d}, {4 * (int)d, (int)d}, {(int)d, 4 * (int)d},
+                            {(int)d, 3 * (int)d}, {4 * (int)d, (int)d}, {(int)d, (int)d}};
+  for (int i = 0; i < 7; ++i) {
+    const size_t w = clipfs_gemm_workspace_floats((int)M, shapes[i][0], shapes[i][1]);
+    ws = w > ws ? w : ws;
+  }
+  S.gemm_ws = o; S.gemm_ws_floats = ws; o += al4(ws);
   S.total = o;
   return S;
 }
@@ -60,10 +69,15 @@ static int check_tower(const clipfs_tower* t, int batch) {
   return CLIPFS_OK;
 }
 
+static thread_local float* g_ws = nullptr;  // split-K scratch of the tower call in progress (its scratch buffer)
+static thread_local size_t g_ws_floats = 0;
+
 static int gemm(const float* A, const float* B, float* C, int M, int N, int K, const float* bias, const float* res,
                 int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r, int nseg,
                 int segw, float lscale, hipStream_t st) {
   clipfs_gemm_args a = {};
+  a.workspace = g_ws;
+  a.workspace_floats = g_ws_floats;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
   a.lda = K; a.ldb = K; a.ldc = N; a.alpha = 1.f;
   a.bias = bias; a.residual = res; a.ldres = N;
@@ -94,6 +108,8 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
   const SavedLayout SL = saved_layout(t, (size_t)M);
   const ScratchLayout SC = scratch_layout(t, (size_t)M);
   const bool train = saved != nullptr;
+  g_ws = scratch + SC.gemm_ws;
+  g_ws_floats = SC.gemm_ws_floats;
   const uint64_t seed = train ? t->dropout_seed : 0;  // dropout only when training (is_training(), :298)
   if (train) {
     hipError_t e = hipMemcpyAsync(saved + SL.x_in, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -144,6 +160,8 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
   const int M = batch * t->seq, d = t->width, r = t->lora_r;
   const SavedLayout SL = saved_layout(t, (size_t)M);
   const ScratchLayout SC = scratch_layout(t, (size_t)M);
+  g_ws = scratch + SC.gemm_ws;
+  g_ws_floats = SC.gemm_ws_floats;
   const uint64_t seed = t->dropout_seed;
   for (int l = t->layers - 1; l >= 0; --l) {
     const clipfs_block& b = t->blocks[l];

@@ -463,6 +463,7 @@ class LoRATrainer:
         self.pg = process_group
         self.rank, self.world = D.world_info(process_group)
         self.shard_text = shard_text and self.world > 1
+        self.overlap_towers = True  # text tower on a side HIP stream (set False to serialise, e.g. for per-kernel timing)
 
     def forward_backward(self, images, captions, target, templates_per_class: int = 1, global_batch: Optional[int] = None):
         """``images`` / ``target`` are THIS RANK's shard of the batch, ``captions`` the full caption table
@@ -477,28 +478,42 @@ class LoRATrainer:
         t = templates_per_class
         classes = captions.shape[0] // t
         c_lo, c_hi = D.shard_bounds(classes, self.rank, self.world) if self.shard_text else (0, classes)
-        emb = tctx = None
-        if c_hi > c_lo:
-            emb, tctx = eng.text_forward(captions[c_lo * t:c_hi * t], self.prompt_ctx, True, seed)
-            txt = ops.class_mean_fwd(emb, c_hi - c_lo, t)
-        if self.shard_text:
-            txt = D.allgather_rows(txt if c_hi > c_lo else None, c_lo, c_hi, classes, m.embed_dim, self.flat.params,
-                                   self.pg)
+        # The two towers are independent until the logits: the text tower runs on a side HIP stream so that
+        # its kernels fill the CUs the image tower's launches leave idle (small per-rank batches) and vice versa.
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_towers else main
+        side.wait_stream(main)
+        emb = tctx = txt = None
+        with torch.cuda.stream(side):
+            if c_hi > c_lo:
+                emb, tctx = eng.text_forward(captions[c_lo * t:c_hi * t], self.prompt_ctx, True, seed)
+                txt = ops.class_mean_fwd(emb, c_hi - c_lo, t)
         feat, ictx = eng.vit_forward(images, True, seed)
         img_n, inv = ops.l2norm_fwd(feat, save_inv=True)
+        main.wait_stream(side)
+        if self.shard_text:
+            txt = D.allgather_rows(txt, c_lo, c_hi, classes, m.embed_dim, self.flat.params, self.pg)
         logits = ops.gemm_nt(img_n, txt, alpha=self.logit_scale)
         loss_sum, dl, correct = ops.cross_entropy(logits, target, True, grad_scale=B / gb)
         d = img_n.shape[1]
         d_img_n = ops.matmul_small(dl, txt, B, d, classes, classes, 1, d, 1, self.logit_scale)
         d_txt = ops.matmul_small(dl, img_n, classes, d, B, 1, classes, d, 1, self.logit_scale)
-        eng.vit_backward(ictx, ops.l2norm_bwd(d_img_n, img_n, inv))
         if self.shard_text:
             D.allreduce_sum_(d_txt, self.pg)  # every rank needs the batch-total gradient of its classes
-        if c_hi > c_lo:
-            d_emb = ops.class_mean_bwd(emb, d_txt[c_lo:c_hi].contiguous(), c_hi - c_lo, t)
-            slot = None if self.prompt_ctx is None else self.prompt_ctx.grad_slot
-            eng.text_backward(tctx, d_emb, slot)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if c_hi > c_lo:
+                d_emb = ops.class_mean_bwd(emb, d_txt[c_lo:c_hi].contiguous(), c_hi - c_lo, t)
+                slot = None if self.prompt_ctx is None else self.prompt_ctx.grad_slot
+                eng.text_backward(tctx, d_emb, slot)
+        eng.vit_backward(ictx, ops.l2norm_bwd(d_img_n, img_n, inv))
+        main.wait_stream(side)
         return loss_sum, correct, logits
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.model.device)
+        return self._side
 
     def optimizer_step(self):
         from clipfs import dist as D

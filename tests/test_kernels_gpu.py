@@ -322,3 +322,29 @@ def test_mta(dev, V, d, Cn):
         _close(mode[i:i + 1], wm, 2e-5, "mta mode")
         _close(logits[i:i + 1], wl, 2e-3, "mta logits")
         assert torch.equal(ops.topk(logits[i:i + 1], 5).cpu().long(), O.jt_topk(wl, 5))
+
+
+def test_gemm_splitk_matches_unsplit(dev):
+    """Few-tile shapes are cut along K (deterministic slab combine): same results as the unsplit kernel to
+    fp32 rounding, epilogue (bias + LoRA + QuickGELU + residual) applied once after the combine."""
+    from clipfs import _lib, ops
+    from oracle import clip_oracle as O
+    M, N, K, r = 300, 384, 1024, 4
+    assert _lib.load().clipfs_gemm_splits(M, N, K) > 1
+    a, w = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5)
+    bias, res = _rand(N, seed=5), _rand(M, N, seed=6)
+    t, lb = _rand(M, 3 * r, seed=7), _rand(N, r, seed=8)
+    D = lambda x: x.float().to(dev)
+    kw = dict(bias=D(bias), residual=D(res), lora_t=D(t), lora_b=D(lb), lora_seg_width=128, lora_scale=0.5, act=1)
+    u1, u2 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    y_split = ops.gemm_nt(D(a), D(w), aux_out=u1, **kw)
+    y_plain = ops.gemm_nt(D(a), D(w), aux_out=u2, split_k=False, **kw)
+    pre = a @ w.t() + bias
+    for s in range(3):
+        pre[:, s * 128:(s + 1) * 128] += 0.5 * t[:, s * r:(s + 1) * r] @ lb[s * 128:(s + 1) * 128].t()
+    want = O.quick_gelu(pre) + res
+    _close(y_split, want, 1e-4, "split-K gemm")
+    _close(u1, pre, 1e-4, "split-K pre-activation")
+    _close(y_split, y_plain.double(), 2e-5, "split vs unsplit")
+    again = ops.gemm_nt(D(a), D(w), aux_out=u1, **kw)
+    assert torch.equal(again, y_split), "split-K combine must be bitwise reproducible"
