@@ -1,0 +1,148 @@
+"""Stage-2 / TTA drop-in modules on the GPU: VLPromptLearner + TextEncoder (slow_pace.py:110-205,828-848),
+Channel_LP / logit_normalize, solve_mta (both return conventions), ood.split_ood and tta.fuse_top5 against the
+oracle on seeded inputs."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _err(a, b):
+    return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def b32(dev):
+    """ViT-B/32-shaped model with the REAL vocabulary (the prompt learner tokenizes real class names)."""
+    from clipfs import synth
+    from jclip.model import build_model
+    import dataclasses
+    cfg = dataclasses.replace(synth.VIT_B32, vision_layers=2, transformer_layers=2)
+    sd = synth.synth_state_dict(cfg, seed=7, perturb=True)
+    return cfg, sd, build_model(sd, device=dev)
+
+
+def test_prompt_learner_and_text_encoder(dev, b32, golden_dir):
+    import os
+    import slow_pace as SP
+    from jclip import clip
+    from oracle import clip_oracle as O
+    cfg, sd, model = b32
+    names = [ln.split()[0] for ln in open(os.path.join(golden_dir, "classes.txt"))][:11]
+    classnames = [n.split("_", 1)[1] if "_" in n else n for n in names]  # dataset prefix stripped (slow_pace.py:1845-1859)
+    pl = SP.VLPromptLearner(classnames, model)
+    assert pl.ctx.shape == (4, 512) and pl.tokenized_prompts.shape == (11, 77)
+    want_ctx = sd["token_embedding.weight"][clip.tokenize("a photo of a")[0, 1:5]]
+    assert _err(pl.ctx, want_ctx) == 0  # initialised from the embeddings of "a photo of a" (:124-131)
+    assert pl.tokenized_prompts[0, 1:5].tolist() == [320, 1125, 539, 320]
+    enc = SP.TextEncoder(model)
+    feats = enc(pl(), pl.tokenized_prompts)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    octx = pl.ctx.detach().double().cpu().requires_grad_()
+    prompts = O.build_prompts(octx, sd64["token_embedding.weight"], pl.tokenized_prompts.cpu())
+    want = O.encode_text(sd64, pl.tokenized_prompts.cpu(), embeds=prompts)
+    assert _err(feats, want) < 2e-5
+    # the materialised [C,77,d] prompt tensor of the reference equals the symbolic PromptBatch
+    assert _err(pl().materialize(model), prompts) < 1e-6
+    # gradient of a scalar of the features with respect to the shared ctx tokens
+    w = torch.randn(11, 512, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    (want * w).sum().backward()
+    (feats * w.float().to(dev)).sum().backward()
+    assert _err(pl.ctx.grad, octx.grad) < 1e-4 * octx.grad.abs().max().item()
+    with pytest.raises(TypeError):
+        enc(prompts.float().to(dev), pl.tokenized_prompts)
+
+
+def test_channel_lp_and_logit_normalize(dev):
+    import slow_pace as SP
+    from oracle import clip_oracle as O
+    g = torch.Generator().manual_seed(3)
+    head = SP.Channel_LP(512, 403, device=dev)
+    with torch.no_grad():
+        head.scale1.copy_(1 + 0.1 * torch.randn(512, generator=g))
+        head.bias1.copy_(0.1 * torch.randn(512, generator=g))
+        head.fc.weight.copy_(torch.randn(403, 512, generator=g) / 512 ** 0.5)  # zero-shot text features go here (:1537-1540)
+    f = torch.randn(37, 512, generator=g)
+    z = head(f.to(dev))
+    want = O.channel_lp(f.double(), head.scale1.detach().double().cpu(), head.bias1.detach().double().cpu(),
+                        head.fc.weight.detach().double().cpu(), head.fc.bias.detach().double().cpu())
+    assert _err(z, want) < 1e-4
+    assert _err(SP.logit_normalize(z), O.logit_normalize(want)) < 1e-4
+
+
+def test_tta_pipeline_views_to_top5(dev, b32):
+    """cfg-4 in miniature: n_img x (1 + N) views -> image tower -> normalise -> MTA -> OOD split / top-5,
+    against the oracle run per image (reference loop: ood.py:867-883, test.py:1705-1742)."""
+    import lora_train_vlp as L
+    import ood
+    import slow_pace as SP
+    import tta
+    from clipfs import ops, synth
+    from oracle import clip_oracle as O
+    cfg, sd, model = b32
+    n_img, V, Cn = 2, 9, 21
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(n_img, 1, 3, 224, 224, generator=g)
+    views = (base + 0.3 * torch.randn(n_img, V, 3, 224, 224, generator=g)).contiguous()
+    text = O.l2_normalize(torch.randn(Cn, 512, generator=g, dtype=torch.float64)).float()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    logits, mode = ood.mta_scores(model, views.to(dev), text.to(dev), want_mode=True)
+    is_base, pred = ood.split_ood(model, views.to(dev), text.to(dev))
+    for i in range(n_img):
+        f = O.l2_normalize(O.encode_image(sd64, views[i].double())).float()
+        wl = O.solve_mta(f, text.t())
+        wm = O.solve_mta(f, text.t(), return_mode=True)
+        assert _err(logits[i:i + 1], wl) < 5e-3
+        assert _err(mode[i:i + 1], wm) < 5e-5
+        assert int(pred[i]) == int(wl.argmax())
+        assert bool(is_base[i]) == bool(O.ood_is_base(wl)[0])
+        # the two reference entry points on one image
+        fg = ops.l2norm_fwd(model.encode_image(views[i].to(dev)).contiguous())
+        assert _err(L.solve_mta(fg, text.t().to(dev)), wl) < 5e-3
+        assert _err(SP.solve_mta(fg, text.t().to(dev)), wm) < 5e-5
+    # fusion (test.py:1729-1742)
+    cos, cos1, cos3 = [torch.randn(n_img, Cn, generator=g) for _ in range(3)]
+    head = torch.randn(n_img, Cn, generator=g)
+    got = tta.fuse_top5(cos.to(dev), cos1.to(dev), cos3.to(dev), head.to(dev))
+    want = O.fuse_top5(cos, cos1, cos3, head)
+    assert torch.equal(got["top5"].cpu().long(), want["top5"])
+    assert _err(got["cos5"], want["cos5"]) < 1e-6 and _err(got["cos4"], want["cos4"]) < 1e-6
+    out = tta.evaluate_views(model, model, views.to(dev), text.to(dev), text.to(dev), text.to(dev))
+    assert out["top5"].shape == (n_img, 5)
+
+
+def test_clip_classifier_and_cls_acc(dev, b32):
+    import lora_train_vlp as L
+    import ood
+    from jclip import clip
+    from oracle import clip_oracle as O
+    cfg, sd, model = b32
+    templates = {0: ["a photo of a cat.", "a picture of a cat."], 1: ["a photo of a dog.", "a picture of a dog."],
+                 2: ["a photo of a bear.", "a picture of a bear."]}
+    w = L.clip_classifier(templates, model)
+    assert w.shape == (1, 3, 512)  # callers do .squeeze(0).t() (lora_train_vlp.py:925-926)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    texts = [t for c in templates for t in templates[c]]
+    emb = O.encode_text(sd64, clip.tokenize(texts))
+    want = O.class_text_features(emb, [0, 0, 1, 1, 2, 2], 3)  # [d, C]
+    assert _err(w.squeeze(0).t(), want) < 2e-5
+    out = torch.tensor([[0.1, 0.9, 0.0], [0.8, 0.1, 0.1], [0.2, 0.3, 0.5], [0.6, 0.3, 0.1]])
+    tgt = torch.tensor([1, 0, 1, 2])
+    assert L.cls_acc(out.to(dev), tgt) == O.cls_acc(out, tgt) == 50.0
+    assert L.cls_acc(out.to(dev), tgt, topk=2) == O.cls_acc(out, tgt, topk=2) == 75.0
+    big = torch.full((3, 403), -1.0)
+    big[0, 372] = 1
+    big[1, 373] = 1
+    big[2, 5] = 1
+    t2 = torch.tensor([3, 400, 390])
+    assert ood.cls_acc(big.to(dev), t2) == O.cls_acc_ood(big, t2)
