@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial-towers", action="store_true",
                     help="run the text and image towers back to back on one stream (default: text tower on a side stream)")
+    ap.add_argument("--trim-text", action="store_true",
+                    help="opt-in: skip the text positions after the batch's last EOT (dead under the causal mask); "
+                         "NOT the headline configuration")
     ap.add_argument("--forward-only", action="store_true", help="time the zero-grad image forward only (diagnostic)")
     return ap.parse_args()
 
@@ -79,6 +82,7 @@ def build_trainer(dev, args, world):
     model.train()
     tr = L.LoRATrainer(model, prompt_ctx=ctx, shard_text=not args.no_shard_text)
     tr.overlap_towers = not args.serial_towers
+    model.engine.trim_text = args.trim_text
     return model, tr, cfg
 
 
@@ -205,7 +209,7 @@ def main():
         lib.clipfs_gemm_timing_collect(ctypes.byref(tms), ctypes.byref(tfl), ctypes.byref(n))
         if n.value > 0 and tms.value > 0:
             ach = tfl.value / (tms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,128> (v_mfma_f32_32x32x2_f32)",
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,128,3> (v_mfma_f32_32x32x2_f32, global_load_lds staging)",
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": n.value, "avg_launch_us": round(tms.value * 1e3 / n.value, 2),
@@ -229,7 +233,7 @@ def main():
                                    "fwd+bwd on 403 captions + image tower fwd+bwd + 100*cos CE + AdamW"
                        if not args.forward_only else "ViT-B/32 image tower forward only (diagnostic)",
                        "global_batch": gb, "images_per_rank": n_img_local, "captions": args.classes,
-                       "lora_dropout": args.dropout, "tower_streams": 1 if args.serial_towers else 2, "parallelism": f"dp{world}" + ("" if args.no_shard_text or world == 1 else "+class-sharded-text")},
+                       "lora_dropout": args.dropout, "tower_streams": 1 if args.serial_towers else 2, "text_positions": "trimmed-to-last-EOT" if args.trim_text else 77, "parallelism": f"dp{world}" + ("" if args.no_shard_text or world == 1 else "+class-sharded-text")},
             "algorithmic_tflop_per_step": round(step_tflop, 3),
             "step_tflops": round(step_tflop / (ms * 1e-3), 2),
             "step_frac_of_fp32_mfma_peak": round(step_tflop / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * world), 4),

@@ -62,7 +62,7 @@ class _TowerRT:
             self._wt[i] = wt
         return wt
 
-    def descriptor(self, train: bool, seed: int) -> Tower:
+    def descriptor(self, train: bool, seed: int, seq: Optional[int] = None) -> Tower:
         blocks = (Block * self.layers)()
         keep = []
         r, scale, p = 0, 0.0, 0.0
@@ -95,7 +95,8 @@ class _TowerRT:
                     b.lora_a_o, b.lora_b_o = _ptr(a.lora_A_o), _ptr(a.lora_B_o)
                     b.g_lora_a_o, b.g_lora_b_o = _ptr(a.grad_A_o), _ptr(a.grad_B_o)
         t = Tower()
-        t.width, t.heads, t.layers, t.seq, t.causal = self.width, self.heads, self.layers, self.seq, int(self.causal)
+        t.width, t.heads, t.layers, t.seq, t.causal = (self.width, self.heads, self.layers, seq or self.seq,
+                                                       int(self.causal))
         t.lora_r, t.lora_scale, t.lora_dropout = r, scale, p
         t.dropout_seed = seed if (train and p > 0) else 0
         t.dropout_stream0 = self.stream0
@@ -119,18 +120,19 @@ class _TowerRT:
             self._bufs[key] = buf
         return buf
 
-    def forward(self, x: torch.Tensor, batch: int, train: bool, seed: int):
+    def forward(self, x: torch.Tensor, batch: int, train: bool, seed: int, seq: Optional[int] = None):
         lib = _lib.load()
-        t = self.descriptor(train, seed)
+        t = self.descriptor(train, seed, seq)
         scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), x.device)
         saved = self.buffer("saved", lib.clipfs_tower_saved_floats(C.byref(t), batch), x.device) if train else None
         check(lib.clipfs_tower_fwd(C.byref(t), x.data_ptr(), batch, _ptr(saved), scratch.data_ptr(),
                                    torch.cuda.current_stream().cuda_stream), "tower_fwd")
         return saved
 
-    def backward(self, dx: torch.Tensor, batch: int, saved: torch.Tensor, seed: int, stop_at_input: bool):
+    def backward(self, dx: torch.Tensor, batch: int, saved: torch.Tensor, seed: int, stop_at_input: bool,
+                 seq: Optional[int] = None):
         lib = _lib.load()
-        t = self.descriptor(True, seed)
+        t = self.descriptor(True, seed, seq)
         scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), dx.device)
         check(lib.clipfs_tower_bwd(C.byref(t), dx.data_ptr(), batch, saved.data_ptr(), scratch.data_ptr(),
                                    int(stop_at_input), torch.cuda.current_stream().cuda_stream), "tower_bwd")
@@ -146,6 +148,11 @@ class Engine:
         self.tproj_t = model.text_projection.data.t().contiguous()   # [E, width]
         self.seed_base = 0x5EED
         self.step = 0
+        # Optional (off by default): run the text tower only on positions <= the last EOT of the batch.  Under the
+        # causal mask nothing after a caption's EOT can influence its EOT feature, nor receive gradient from it, so
+        # the reference's rows EOT+1..76 (jclip/model.py:202-215 encodes all 77) are dead work.
+        self.trim_text = False
+        self._trim_cache = {}
 
     # -- seeds ------------------------------------------------------------------------------------
     def next_seed(self) -> int:
@@ -204,15 +211,28 @@ class Engine:
             ops.token_rows_grad(dx0, v.VPT.grad_slot, B, L, 1 + P)
 
     # -- text tower --------------------------------------------------------------------------------
+    def _effective_ids(self, ids: torch.Tensor):
+        """(ids possibly truncated to the batch's last EOT, effective sequence length)."""
+        if not self.trim_text:
+            return ids, ids.shape[1]
+        key = (ids.data_ptr(), tuple(ids.shape), ids._version)
+        hit = self._trim_cache.get(key)
+        if hit is None:
+            leff = int(ids.argmax(dim=-1).max().item()) + 1  # one host sync per distinct caption table
+            hit = (ids[:, :leff].contiguous(), leff)
+            self._trim_cache = {key: hit}
+        return hit
+
     def text_forward(self, ids: torch.Tensor, prompt_ctx: Optional[torch.Tensor], train: bool, seed: int = 0):
         m = self.model
         ids = ids.to(device=m.device, dtype=torch.int64).contiguous()
         n, seq = ids.shape
         if seq != m.context_length:
             raise ValueError(f"expected token ids [N,{m.context_length}], got {tuple(ids.shape)}")
+        ids, seq = self._effective_ids(ids)
         x = ops.text_embed(ids, m.token_embedding.weight.data, m.positional_embedding.data,
                            None if prompt_ctx is None else prompt_ctx.data)
-        saved = self.txt.forward(x, n, train, seed)
+        saved = self.txt.forward(x, n, train, seed, seq)
         rows, idx = ops.gather_eot(x, ids)
         if train:
             y, mean, rstd = ops.layernorm_fwd(rows, m.ln_final.weight.data, m.ln_final.bias.data, save_stats=True)
@@ -222,18 +242,18 @@ class Engine:
         feat = ops.gemm_nt(y, self.tproj_t)
         ctx = None
         if train:
-            ctx = dict(n=n, rows=rows, idx=idx, stats=(mean, rstd), saved=saved, seed=seed,
+            ctx = dict(n=n, seq=seq, rows=rows, idx=idx, stats=(mean, rstd), saved=saved, seed=seed,
                        has_ctx=prompt_ctx is not None)
         return feat, ctx
 
     def text_backward(self, ctx: dict, dfeat: torch.Tensor, dctx_slot: Optional[torch.Tensor] = None) -> None:
         m = self.model
-        n, seq = ctx["n"], m.context_length
+        n, seq = ctx["n"], ctx["seq"]
         dy = ops.gemm_nt(dfeat.contiguous(), m.text_projection.data)
         mean, rstd = ctx["stats"]
         drows = ops.layernorm_bwd(dy, ctx["rows"], m.ln_final.weight.data, mean, rstd)
         dx = ops.scatter_rows(drows, ctx["idx"], seq)
-        self.txt.backward(dx, n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"])
+        self.txt.backward(dx, n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"], seq=seq)
         if ctx["has_ctx"]:
             assert dctx_slot is not None
             ops.token_rows_grad(dx, dctx_slot, n, seq, 1)

@@ -319,3 +319,32 @@ def test_save_load_roundtrip(dev, monkeypatch, tmp_path):
         L.load_lora(bad, layers2, path)
     with pytest.raises(FileNotFoundError):
         L.load_lora(args, layers2, path + ".missing")
+
+
+def test_trim_text_is_exact(dev, monkeypatch):
+    """Engine.trim_text: positions after the batch's last EOT are dead under the causal mask -- features,
+    loss and every gradient equal the full 77-position run."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    cfg = synth.SMALL
+    outs = []
+    for trim in (False, True):
+        sd, model = _build(cfg, dev)
+        args = _args("small", r=4)
+        _apply(model, cfg, args, synth.synth_lora(cfg, 4, seed=5), monkeypatch)
+        model.eval()
+        model.engine.trim_text = trim
+        cap = synth.synth_captions(9, cfg.context_length, cfg.vocab_size, seed=4, max_len=9)
+        img = synth.synth_images(6, cfg.image_resolution, seed=3)
+        tgt = synth.synth_labels(6, 9, seed=2)
+        ctx = torch.nn.Parameter(sd["token_embedding.weight"][[5, 6, 7, 8]].clone().to(dev))
+        tr = L.LoRATrainer(model, prompt_ctx=ctx)
+        tr.flat.zero_grad()
+        ls, _, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+        with torch.no_grad():
+            ft = model.encode_text(cap.to(dev))
+        outs.append((logits.cpu(), tr.flat.grads.cpu().clone(), ft.cpu(), ls.item()))
+    assert int(cap.argmax(-1).max()) + 1 < cfg.context_length  # the test really trims something
+    (l0, g0, f0, s0), (l1, g1, f1, s1) = outs
+    assert (f0 - f1).abs().max() < 1e-6 and (l0 - l1).abs().max() < 1e-4 and abs(s0 - s1) < 1e-5
+    assert (g0 - g1).abs().max() < 1e-6 * max(g0.abs().max().item(), 1.0)
