@@ -64,24 +64,27 @@ __device__ __forceinline__ void col_to_regs(const float* __restrict__ base, size
 }
 
 // dot of the wave-uniform global row `u` (64 floats) with each of this lane's register rows
+// (`nkeys` = number of keys that are not masked for this row: key blocks of 64 beyond it are skipped)
 template <int KPL>
-__device__ __forceinline__ void dot_rows(const float* __restrict__ u, const float (&reg)[KPL][HD], float (&out)[KPL]) {
-  float a0[KPL], a1[KPL];
+__device__ __forceinline__ void dot_rows(const float* __restrict__ u, const float (&reg)[KPL][HD], float (&out)[KPL],
+                                         int nkeys = 64 * KPL) {
+  f32x4 q[HD / 4];
 #pragma unroll
-  for (int kk = 0; kk < KPL; ++kk) a0[kk] = a1[kk] = 0.f;
+  for (int c = 0; c < HD / 4; ++c) q[c] = *reinterpret_cast<const f32x4*>(u + 4 * c);  // same address in every lane
 #pragma unroll
-  for (int c = 0; c < HD / 4; ++c) {
-    const f32x4 q = *reinterpret_cast<const f32x4*>(u + 4 * c);  // same address in every lane
+  for (int kk = 0; kk < KPL; ++kk) {
+    float a0 = 0.f, a1 = 0.f;
+    if (64 * kk < nkeys) {  // wave-uniform
 #pragma unroll
-    for (int kk = 0; kk < KPL; ++kk) {
-      a0[kk] = fmaf(q[0], reg[kk][4 * c + 0], a0[kk]);
-      a1[kk] = fmaf(q[1], reg[kk][4 * c + 1], a1[kk]);
-      a0[kk] = fmaf(q[2], reg[kk][4 * c + 2], a0[kk]);
-      a1[kk] = fmaf(q[3], reg[kk][4 * c + 3], a1[kk]);
+      for (int c = 0; c < HD / 4; ++c) {
+        a0 = fmaf(q[c][0], reg[kk][4 * c + 0], a0);
+        a1 = fmaf(q[c][1], reg[kk][4 * c + 1], a1);
+        a0 = fmaf(q[c][2], reg[kk][4 * c + 2], a0);
+        a1 = fmaf(q[c][3], reg[kk][4 * c + 3], a1);
+      }
     }
+    out[kk] = a0 + a1;
   }
-#pragma unroll
-  for (int kk = 0; kk < KPL; ++kk) out[kk] = a0[kk] + a1[kk];
 }
 
 // scores -> probabilities for query row i (lane = key): scale after the dot (mha.py:79), mask, softmax
@@ -111,11 +114,11 @@ __device__ __forceinline__ void softmax_row(float (&s)[KPL], int i, int lane, in
 // Guarded in groups of 16 (4 reads in flight per group); vec must be finite up to the group boundary and
 // col[j >= L] == 0, so the overhang contributes exact zeros.
 template <int LMAX>
-__device__ __forceinline__ float bcast_dot(const float* __restrict__ vec, const float (&col)[LMAX], int n) {
+__device__ __forceinline__ float bcast_dot(const float* __restrict__ vec, const float (&col)[LMAX], int n, int lo = 0) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
   for (int g = 0; g < LMAX / 16; ++g) {
-    if (16 * g < n) {
+    if (16 * g < n && 16 * g + 16 > lo) {  // entries below lo are exact zeros (causal mask) in vec
       f32x4 p[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) p[t] = *reinterpret_cast<const f32x4*>(vec + 16 * g + 4 * t);
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(512) void attention_fwd_kernel(const float* __restr
     float* myP = sP + wave * PROW;
     for (int i = wave; i < L; i += NW) {
       float s[KPL];
-      dot_rows<KPL>(q0 + (size_t)i * ld, krow, s);
+      dot_rows<KPL>(q0 + (size_t)i * ld, krow, s, causal ? i + 1 : L);
       softmax_row<KPL>(s, i, lane, L, causal);
       myP[lane] = s[0];
       __builtin_amdgcn_wave_barrier();  // same wave writes then reads: LDS is in order per wave
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const float* __restr
     // A1: probabilities
     for (int i = wave; i < L; i += NW) {
       float s[KPL];
-      dot_rows<KPL>(q0 + (size_t)i * ld, rows, s);
+      dot_rows<KPL>(q0 + (size_t)i * ld, rows, s, causal ? i + 1 : L);
       softmax_row<KPL>(s, i, lane, L, causal);
 #pragma unroll
       for (int kk = 0; kk < KPL; ++kk) {
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const float* __restr
     // A2: dP, dS
     for (int i = wave; i < L; i += NW) {
       float dp[KPL], pv[KPL];
-      dot_rows<KPL>(do0 + (size_t)i * d, rows, dp);
+      dot_rows<KPL>(do0 + (size_t)i * d, rows, dp, causal ? i + 1 : L);
       float rs = 0.f;
 #pragma unroll
       for (int kk = 0; kk < KPL; ++kk) {
@@ -298,8 +301,9 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const float* __restr
     col_to_regs<LMAX>(do0, (size_t)d, lane, L, doc);
     col_to_regs<LMAX>(q0, ld, lane, L, qc);
     for (int j = wave; j < L; j += NW) {
-      const float av = bcast_dot<LMAX>(sPT + j * LP, doc, L);
-      const float ak = bcast_dot<LMAX>(sdST + j * LP, qc, L);
+      const int lo = causal ? j : 0;  // P_ij = dS_ij = 0 for i < j
+      const float av = bcast_dot<LMAX>(sPT + j * LP, doc, L, lo);
+      const float ak = bcast_dot<LMAX>(sdST + j * LP, qc, L, lo);
       dq0[(size_t)j * ld + 2 * d + lane] = av;
       dq0[(size_t)j * ld + d + lane] = ak;
     }
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const float* __restr
     // C2: dQ[i] = sum_j dS_ij K_j
     float kc[LMAX];
     col_to_regs<LMAX>(q0 + d, ld, lane, L, kc);
-    for (int i = wave; i < L; i += NW) dq0[(size_t)i * ld + lane] = bcast_dot<LMAX>(sdS + i * LP, kc, L);
+    for (int i = wave; i < L; i += NW) dq0[(size_t)i * ld + lane] = bcast_dot<LMAX>(sdS + i * LP, kc, causal ? i + 1 : L);
   }
 }
 
