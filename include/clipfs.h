@@ -75,6 +75,8 @@ typedef struct clipfs_gemm_args {
   float lora_scale;
   int a_mode;              /* 0 dense, 1 patch im2col */
   int img_res, patch, out_tokens; /* a_mode 1 */
+  const void* B_planes;    /* optional: B pre-split into bf16 hi/lo planes (clipfs_split_bf16): selects the
+                              split-bf16 x3 MFMA kernel (a_mode 0, K % 32 == 0, ldb == K); NULL = exact fp32 */
   float* workspace;        /* optional split-K scratch (NULL: never split); see clipfs_gemm_workspace_floats */
   size_t workspace_floats;
 } clipfs_gemm_args;
@@ -83,6 +85,10 @@ int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
  * whose raw partial sums go to `workspace` and are combined, in slice order, by a second kernel that applies
  * the epilogue -- deterministic, no float atomics.  workspace_floats >= clipfs_gemm_workspace_floats(M,N,K)
  * enables it; 0 is returned for shapes that are never split. */
+/* planes[0..n) = bf16(src), planes[n..2n) = bf16(src - hi): the frozen-weight half of the opt-in split-bf16
+ * ("bf16 x 3") GEMM: a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+ * `planes` holds 2*n bf16 values (4*n bytes); n % 8 == 0. */
+int clipfs_split_bf16(const float* src, void* planes, size_t n, void* stream);
 int clipfs_gemm_splits(int M, int N, int K);
 size_t clipfs_gemm_workspace_floats(int M, int N, int K);
 /* Diagnostics for bench.py's roofline leg (never enabled inside a timed region): while enabled, every
@@ -217,6 +223,9 @@ typedef struct clipfs_block {
   const float *lora_a_qkv, *lora_b_qkv, *lora_a_o, *lora_b_o;
   float *g_lora_a_qkv, *g_lora_b_qkv, *g_lora_a_o, *g_lora_b_o; /* gradient slots (accumulated into) */
   unsigned lora_mask;                   /* bit0 q, bit1 k, bit2 v, bit3 o */
+  /* optional bf16 hi/lo planes of the four weights and of their transposed copies (clipfs_split_bf16); when
+   * present the tower's GEMMs use the split-bf16 x3 kernel, otherwise the exact fp32 MFMA kernel */
+  const void *w_qkv_p, *w_o_p, *w_fc_p, *w_pr_p, *w_qkv_t_p, *w_o_t_p, *w_fc_t_p, *w_pr_t_p;
 } clipfs_block;
 
 typedef struct clipfs_tower {

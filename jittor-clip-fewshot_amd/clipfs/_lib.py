@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
         ("lora_r", C.c_int), ("lora_nseg", C.c_int), ("lora_seg_width", C.c_int),
         ("lora_scale", C.c_float),
         ("a_mode", C.c_int), ("img_res", C.c_int), ("patch", C.c_int), ("out_tokens", C.c_int),
-        ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t),
+        ("B_planes", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t),
     ]
 
 
@@ -44,7 +44,8 @@ class Block(C.Structure):
         "w_fc", "b_fc", "w_fc_t",
         "w_pr", "b_pr", "w_pr_t",
         "lora_a_qkv", "lora_b_qkv", "lora_a_o", "lora_b_o",
-        "g_lora_a_qkv", "g_lora_b_qkv", "g_lora_a_o", "g_lora_b_o")] + [("lora_mask", C.c_uint)]
+        "g_lora_a_qkv", "g_lora_b_qkv", "g_lora_a_o", "g_lora_b_o")] + [("lora_mask", C.c_uint)] + [
+        (n, C.c_void_p) for n in ("w_qkv_p", "w_o_p", "w_fc_p", "w_pr_p", "w_qkv_t_p", "w_o_t_p", "w_fc_t_p", "w_pr_t_p")]
 
 
 class Tower(C.Structure):
@@ -65,6 +66,7 @@ SIGNATURES = {
     "clipfs_abi_version": (_i, []),
     "clipfs_last_error": (C.c_char_p, []),
     "clipfs_gemm_nt": (_i, [C.POINTER(GemmArgs), _p]),
+    "clipfs_split_bf16": (_i, [_p, _p, _sz, _p]),
     "clipfs_gemm_splits": (_i, [_i, _i, _i]),
     "clipfs_gemm_workspace_floats": (_sz, [_i, _i, _i]),
     "clipfs_gemm_timing": (_i, [_i]),

@@ -46,6 +46,8 @@ class _TowerRT:
         self._keep: list = []
         self._bufs: Dict[Tuple[str, int], torch.Tensor] = {}
         self._wt: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._planes: Dict[Tuple[int, str], torch.Tensor] = {}
+        self.precision = "fp32"  # "fp32": exact v_mfma_f32_32x32x2_f32 | "bf16x3": split-bf16, 3 MFMA products
         self.lora_r = 0
         self.lora_scale = 0.0
         self.lora_dropout = 0.0
@@ -61,6 +63,14 @@ class _TowerRT:
                   "fc": blk.mlp.c_fc.weight.data.t().contiguous(), "pr": blk.mlp.c_proj.weight.data.t().contiguous()}
             self._wt[i] = wt
         return wt
+
+    def _plane(self, i: int, name: str, w: torch.Tensor) -> torch.Tensor:
+        key = (i, name)
+        pl = self._planes.get(key)
+        if pl is None:
+            pl = ops.split_bf16(w.contiguous())
+            self._planes[key] = pl
+        return pl
 
     def descriptor(self, train: bool, seed: int, seq: Optional[int] = None) -> Tower:
         blocks = (Block * self.layers)()
@@ -83,6 +93,16 @@ class _TowerRT:
             if train:
                 wt = self._transposed(i, blk)
                 b.w_qkv_t, b.w_o_t, b.w_fc_t, b.w_pr_t = _ptr(wt["qkv"]), _ptr(wt["o"]), _ptr(wt["fc"]), _ptr(wt["pr"])
+            if self.precision == "bf16x3":
+                b.w_qkv_p = _ptr(self._plane(i, "qkv", w_qkv.data))
+                b.w_o_p = _ptr(self._plane(i, "o", w_o.data))
+                b.w_fc_p = _ptr(self._plane(i, "fc", blk.mlp.c_fc.weight.data))
+                b.w_pr_p = _ptr(self._plane(i, "pr", blk.mlp.c_proj.weight.data))
+                if train:
+                    b.w_qkv_t_p = _ptr(self._plane(i, "qkv_t", wt["qkv"]))
+                    b.w_o_t_p = _ptr(self._plane(i, "o_t", wt["o"]))
+                    b.w_fc_t_p = _ptr(self._plane(i, "fc_t", wt["fc"]))
+                    b.w_pr_t_p = _ptr(self._plane(i, "pr_t", wt["pr"]))
             b.lora_mask = 0
             if lora and a.r > 0:
                 if r and (a.r != r or abs(a.scaling - scale) > 0 or abs(a.dropout_rate - p) > 0):
@@ -153,6 +173,21 @@ class Engine:
         # the reference's rows EOT+1..76 (jclip/model.py:202-215 encodes all 77) are dead work.
         self.trim_text = False
         self._trim_cache = {}
+
+    @property
+    def precision(self) -> str:
+        return self.vis.precision
+
+    @precision.setter
+    def precision(self, mode: str) -> None:
+        """"fp32" (default): every GEMM on the exact fp32 MFMA.  "bf16x3": the tower GEMMs (97 % of the FLOPs) run
+        as split-bf16 with three bf16 MFMA products per operand pair, fp32 accumulate (weights are split once;
+        logits move by ~2e-4 on 100 x cosine, inside the 1e-3 budget).  LayerNorm, attention, LoRA, the patch /
+        projection / logits GEMMs and all reductions stay fp32."""
+        if mode not in ("fp32", "bf16x3"):
+            raise ValueError("precision must be 'fp32' or 'bf16x3'")
+        self.vis.precision = mode
+        self.txt.precision = mode
 
     # -- seeds ------------------------------------------------------------------------------------
     def next_seed(self) -> int:

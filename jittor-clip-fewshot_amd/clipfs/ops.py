@@ -30,7 +30,7 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
             act: int = 0, aux_out=None, aux_in=None, alpha: float = 1.0, lora_t=None, lora_b=None,
-            lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True) -> torch.Tensor:
+            lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True, b_planes=None) -> torch.Tensor:
     """out = epi(alpha * a @ b.T); a [M,K], b [N,K]."""
     _f32(a), _f32(b)
     M, K = a.shape
@@ -56,6 +56,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         g.lora_nseg = lora_t.shape[1] // r
         g.lora_seg_width = lora_seg_width or N
         g.lora_scale = lora_scale
+    g.B_planes = _p(b_planes)
     lib = _lib.load()
     ws = None
     nws = lib.clipfs_gemm_workspace_floats(M, N, K) if split_k else 0
@@ -64,6 +65,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         g.workspace, g.workspace_floats = _p(ws), nws
     check(lib.clipfs_gemm_nt(C.byref(g), _stream()), "gemm_nt")
     return out
+
+
+def split_bf16(w: torch.Tensor) -> torch.Tensor:
+    """hi/lo bf16 planes of a frozen fp32 weight: int16 tensor [2, *w.shape] (bit patterns)."""
+    _f32(w)
+    planes = torch.empty((2,) + tuple(w.shape), device=w.device, dtype=torch.int16)
+    check(_lib.load().clipfs_split_bf16(_p(w), _p(planes), w.numel(), _stream()), "split_bf16")
+    return planes
 
 
 def patch_embed(images: torch.Tensor, conv_w: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, tokens: int) -> None:

@@ -15,6 +15,7 @@
 // Ragged M and N are handled by clamping the staged row index and predicating the stores; a K tail
 // (K % 32 != 0) is zero filled.  Epilogue order is documented in include/clipfs.h.
 #include "common.h"
+#include "gemm_common.h"
 
 #include <stdlib.h>
 
@@ -24,46 +25,6 @@ namespace clipfs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // first-class vector: stays in VGPRs (HIP's float4 struct arrays went to scratch)
-
-struct GemmParams {
-  clipfs_gemm_args a;
-  int n_blocks_n;  // number of BN-wide column blocks
-  int patches;     // a_mode 1: patches per image (G*G)
-  int grid_g;      // a_mode 1: patches per side
-  int splits;      // split-K factor (1 = none): unit u = tile * splits + split, split s covers K-steps [s*nk/S, (s+1)*nk/S)
-  float* part;     // splits > 1: raw partial sums, slab s at part + s * M * N (row-major, ld = N)
-  int ablate;      // tuning aid (CLIPFS_GEMM_ABLATE): 1 no global prefetch, 2 no LDS store, 4 no barrier -- WRONG RESULTS
-};
-
-constexpr int BK = 32;
-
-// The fused epilogue for one output element (order documented in include/clipfs.h); used by the GEMM
-// kernel and by the split-K combine kernel.
-__device__ __forceinline__ void epilogue_store(const clipfs_gemm_args& g, int patches, int m, int n, float accv) {
-  float v = g.alpha * accv + (g.bias ? g.bias[n] : 0.f);
-  if (g.lora_t) {
-    const int lseg = n / g.lora_seg_width;
-    const float* lb = g.lora_b + (size_t)n * g.lora_r;
-    const float* t = g.lora_t + (size_t)m * (g.lora_nseg * g.lora_r) + lseg * g.lora_r;
-    float d = 0.f;
-    for (int jj = 0; jj < g.lora_r; ++jj) d = fmaf(t[jj], lb[jj], d);
-    v = fmaf(g.lora_scale, d, v);
-  }
-  size_t orow = (size_t)m, rrow = (size_t)m;
-  if (g.a_mode == 1) {
-    const int b = m / patches, pp = m - b * patches;
-    orow = (size_t)b * g.out_tokens + 1 + pp;
-    rrow = (size_t)(1 + pp);
-  }
-  if (g.act == 1) {
-    if (g.aux_out) g.aux_out[orow * g.ldc + n] = v;
-    v = quick_gelu(v);
-  } else if (g.act == 2) {
-    v *= quick_gelu_grad(g.aux_in[orow * g.ldc + n]);
-  }
-  if (g.residual) v += g.residual[rrow * g.ldres + n];
-  g.C[orow * g.ldc + n] = v;
-}
 
 // 16-byte global -> LDS copy without a VGPR round trip (global_load_lds_dwordx4): the LDS destination is
 // wave-uniform base + lane * 16, the global source is per lane -- so the XOR swizzle goes on the SOURCE.
@@ -342,19 +303,7 @@ static int launch(const GemmParams& p, hipStream_t stream) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  TimedLaunch tl;
-  if (g_timing) {
-    (void)hipEventCreate(&tl.start);
-    (void)hipEventCreate(&tl.stop);
-    tl.flops = 2.0 * p.a.M * (double)p.a.N * p.a.K;
-    (void)hipEventRecord(tl.start, stream);
-  }
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, AMODE>), dim3(mb * p.n_blocks_n * p.splits), dim3(256), lds, stream, p);
-  if (g_timing) {
-    (void)hipEventRecord(tl.stop, stream);
-    if (!g_timed) g_timed = new std::vector<TimedLaunch>();
-    g_timed->push_back(tl);
-  }
   CLIPFS_CHECK(launch_status());
   if (p.splits > 1) {
     const size_t total = (size_t)p.a.M * p.a.N;
@@ -418,7 +367,27 @@ extern "C" int clipfs_gemm_timing_collect(double* total_ms, double* total_flops,
   return CLIPFS_OK;
 }
 
+namespace clipfs {
+int gemm_bf16x3_dispatch(const GemmParams& base, hipStream_t stream);  // gemm_bf16.hip
+}
+
+static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream);
+
 extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
+  if (!g_timing) return gemm_nt_impl(args, stream);
+  TimedLaunch tl;
+  (void)hipEventCreate(&tl.start);
+  (void)hipEventCreate(&tl.stop);
+  tl.flops = args ? 2.0 * args->M * (double)args->N * args->K : 0.0;
+  (void)hipEventRecord(tl.start, (hipStream_t)stream);
+  const int rc = gemm_nt_impl(args, stream);
+  (void)hipEventRecord(tl.stop, (hipStream_t)stream);
+  if (!g_timed) g_timed = new std::vector<TimedLaunch>();
+  g_timed->push_back(tl);
+  return rc;
+}
+
+static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   CLIPFS_REQUIRE(args != nullptr, "gemm: null args");
   const clipfs_gemm_args& a = *args;
   CLIPFS_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
@@ -452,6 +421,8 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   p.splits = 1;
   p.part = nullptr;
+  p.n_blocks_n = 0;
+  if (a.B_planes && a.a_mode == 0 && (a.K % BK) == 0 && a.ldb == a.K) return gemm_bf16x3_dispatch(p, s);
   {
     const int want = clipfs_gemm_splits(a.M, a.N, a.K);
     if (want > 1 && a.workspace && a.workspace_floats >= (size_t)want * a.M * a.N) {

@@ -72,10 +72,11 @@ static int check_tower(const clipfs_tower* t, int batch) {
 static thread_local float* g_ws = nullptr;  // split-K scratch of the tower call in progress (its scratch buffer)
 static thread_local size_t g_ws_floats = 0;
 
-static int gemm(const float* A, const float* B, float* C, int M, int N, int K, const float* bias, const float* res,
-                int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r, int nseg,
-                int segw, float lscale, hipStream_t st) {
+static int gemm(const float* A, const float* B, const void* Bp, float* C, int M, int N, int K, const float* bias,
+                const float* res, int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r,
+                int nseg, int segw, float lscale, hipStream_t st) {
   clipfs_gemm_args a = {};
+  a.B_planes = Bp;
   a.workspace = g_ws;
   a.workspace_floats = g_ws_floats;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
@@ -134,19 +135,19 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
                                       train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
     if (qkv_mask)
       CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, st));
-    CLIPFS_CHECK(gemm(h1, b.w_qkv, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
+    CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
                       b.lora_b_qkv, r, 3, d, t->lora_scale, st));
     CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, batch, t->seq, t->heads, t->causal, st));
     if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, st));
-    CLIPFS_CHECK(gemm(att, b.w_o, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
+    CLIPFS_CHECK(gemm(att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
                       1, d, t->lora_scale, st));
     float* h2 = scratch + SC.h;
     CLIPFS_CHECK(clipfs_layernorm_fwd(x_mid, d, b.ln2_g, b.ln2_b, h2, train ? sv + SL.stat2 : nullptr,
                                       train ? sv + SL.stat2 + M : nullptr, M, d, 1e-5f, st));
     float* gbuf = scratch + SC.big;
-    CLIPFS_CHECK(gemm(h2, b.w_fc, gbuf, M, 4 * d, d, b.b_fc, nullptr, 1, train ? sv + SL.u : nullptr, nullptr, nullptr,
+    CLIPFS_CHECK(gemm(h2, b.w_fc, b.w_fc_p, gbuf, M, 4 * d, d, b.b_fc, nullptr, 1, train ? sv + SL.u : nullptr, nullptr, nullptr,
                       nullptr, 0, 0, 0, 0.f, st));
-    CLIPFS_CHECK(gemm(gbuf, b.w_pr, x_next, M, d, 4 * d, b.b_pr, x_mid, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+    CLIPFS_CHECK(gemm(gbuf, b.w_pr, b.w_pr_p, x_next, M, d, 4 * d, b.b_pr, x_mid, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
                       0.f, st));
   }
   return CLIPFS_OK;
@@ -177,14 +178,14 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     float* dt = scratch + SC.dt;
     float* work = scratch + SC.work;
     // MLP: du = (dx Wpr) * gelu'(u) ; dh2 = du Wfc ; dx += LN2'(dh2)
-    CLIPFS_CHECK(gemm(dx, b.w_pr_t, du, M, 4 * d, d, nullptr, nullptr, 2, nullptr, sv + SL.u, nullptr, nullptr, 0, 0, 0,
+    CLIPFS_CHECK(gemm(dx, b.w_pr_t, b.w_pr_t_p, du, M, 4 * d, d, nullptr, nullptr, 2, nullptr, sv + SL.u, nullptr, nullptr, 0, 0, 0,
                       0.f, st));
-    CLIPFS_CHECK(gemm(du, b.w_fc_t, dh, M, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
+    CLIPFS_CHECK(gemm(du, b.w_fc_t, b.w_fc_t_p, dh, M, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
                       st));
     CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, d, M, d,
                                       st));
     // attention output projection
-    CLIPFS_CHECK(gemm(dx, b.w_o_t, datt, M, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
+    CLIPFS_CHECK(gemm(dx, b.w_o_t, b.w_o_t_p, datt, M, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
                       st));
     if (lora_o) {
       CLIPFS_REQUIRE(b.g_lora_a_o && b.g_lora_b_o, "tower_bwd: block %d o-LoRA gradient slots missing", l);
@@ -194,7 +195,7 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, dqkv, batch, t->seq, t->heads, t->causal, st));
     const bool need_dx = !(l == 0 && stop_at_input);
     if (need_dx)
-      CLIPFS_CHECK(gemm(dqkv, b.w_qkv_t, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+      CLIPFS_CHECK(gemm(dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
                         0.f, st));
     if (qkv_mask) {
       CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);

@@ -60,7 +60,7 @@ def main():
     print(f"lora_down +dropout: {t*1e6:.1f} us")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
 
 
@@ -82,3 +82,21 @@ def lora_bench():
 
 if __name__ == "__main__" and "--lora" in sys.argv:
     lora_bench()
+
+
+def bf16_bench():
+    shapes = [("qkv", 12800, 2304, 768), ("out", 12800, 768, 768), ("fc", 12800, 3072, 768), ("proj", 12800, 768, 3072),
+              ("t_qkv", 31031, 1536, 512), ("t_out", 31031, 512, 512), ("t_fc", 31031, 2048, 512),
+              ("t_proj", 31031, 512, 2048), ("sq4096", 4096, 4096, 4096)]
+    for name, M, N, K in shapes:
+        a = torch.randn(M, K, device=dev)
+        b = torch.randn(N, K, device=dev)
+        out = torch.empty(M, N, device=dev)
+        planes = ops.split_bf16(b)
+        t0 = timeit(lambda: ops.gemm_nt(a, b, out))
+        t1 = timeit(lambda: ops.gemm_nt(a, b, out, b_planes=planes))
+        print(f"gemm {name:7s} fp32 {t0*1e6:8.1f} us {2*M*N*K/t0/1e12:6.1f} TF | bf16x3 {t1*1e6:8.1f} us {2*M*N*K/t1/1e12:6.1f} TF  x{t0/t1:.2f}")
+
+
+if __name__ == "__main__" and "--bf16" in sys.argv:
+    bf16_bench()

@@ -348,3 +348,43 @@ def test_trim_text_is_exact(dev, monkeypatch):
     (l0, g0, f0, s0), (l1, g1, f1, s1) = outs
     assert (f0 - f1).abs().max() < 1e-6 and (l0 - l1).abs().max() < 1e-4 and abs(s0 - s1) < 1e-5
     assert (g0 - g1).abs().max() < 1e-6 * max(g0.abs().max().item(), 1.0)
+
+
+def test_bf16x3_precision_mode(dev, monkeypatch):
+    """Opt-in split-bf16 GEMM mode on the full ViT-B/32 + text towers with the shipped LoRA: logits stay inside the
+    north-star tolerance (1e-3 on 100 x cosine) of the fp64 oracle and top-5 labels agree; LoRA gradients of a
+    train step agree with the exact-fp32 engine to ~1e-3 relative."""
+    import os
+    import lora_train_vlp as L
+    from clipfs import safe_pkl, synth
+    from oracle import clip_oracle as O
+    cfg = synth.VIT_B32
+    sd, model = _build(cfg, dev, seed=1234)
+    args = _args("ViT-B/32", r=4, p=0.0)
+    layers = L.apply_lora(args, model)
+    golden = os.path.join(os.path.dirname(__file__), "golden", "lora_weights.pkl")
+    L.load_lora(args, layers, golden)
+    ck = safe_pkl.load(golden)
+    tl, vl = O.split_lora_checkpoint(ck["weights"], "both", "all", "ViT-B/32")
+    B, Cn = 8, 16
+    img = synth.synth_images(B, 224, seed=0)
+    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=1)
+    tgt = synth.synth_labels(B, Cn, seed=2)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    with torch.no_grad():
+        wi = O.l2_normalize(O.encode_image(sd64, img.double(), vl, 0.5))
+        wl = 100.0 * wi @ O.l2_normalize(O.encode_text(sd64, cap, tl, 0.5)).t()
+    model.eval()
+    res = {}
+    for mode in ("fp32", "bf16x3"):
+        model.engine.precision = mode
+        tr = L.LoRATrainer(model) if mode == "fp32" else tr
+        tr.flat.zero_grad()
+        _, _, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+        res[mode] = (logits.double().cpu(), tr.flat.grads.double().cpu().clone())
+    e32, e16 = _err(res["fp32"][0], wl), _err(res["bf16x3"][0], wl)
+    assert e32 < 1e-4 and e16 < 1e-3, (e32, e16)
+    assert e16 > e32  # the mode really switched
+    assert torch.equal(L.ops.topk(res["bf16x3"][0].float().to(dev), 5).cpu().long(), O.jt_topk(wl.float(), 5))
+    g32, g16 = res["fp32"][1], res["bf16x3"][1]
+    assert (g32 - g16).abs().max() < 3e-3 * g32.abs().max()

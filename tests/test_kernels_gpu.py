@@ -348,3 +348,25 @@ def test_gemm_splitk_matches_unsplit(dev):
     _close(y_split, y_plain.double(), 2e-5, "split vs unsplit")
     again = ops.gemm_nt(D(a), D(w), aux_out=u1, **kw)
     assert torch.equal(again, y_split), "split-K combine must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 384, 128), (1000, 768, 768), (130, 403, 512)])
+def test_gemm_bf16x3(dev, M, N, K):
+    """Opt-in split-bf16 GEMM (3 bf16 MFMA products per operand pair): relative error ~1e-5 of the row/column
+    norms -- between bf16 (4e-3) and exact fp32 (1e-7) -- and the fused epilogue is the fp32 one."""
+    from clipfs import ops
+    a, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    bias, res = _rand(N, seed=5), _rand(M, N, seed=6)
+    D = lambda x: x.float().to(dev)
+    planes = ops.split_bf16(D(w))
+    hi = planes[0].view(torch.bfloat16).float().cpu().double()
+    lo = planes[1].view(torch.bfloat16).float().cpu().double()
+    w32 = w.float().double()
+    assert (hi - w32.bfloat16().double()).abs().max() == 0           # hi = RNE bf16 of the weight
+    assert (hi + lo - w32).abs().max() <= 2.0 ** -16 * w32.abs().max()    # two planes carry ~16 mantissa bits
+    out = ops.gemm_nt(D(a), D(w), bias=D(bias), residual=D(res), b_planes=planes)
+    want = a @ w.t() + bias + res
+    err = (out.double().cpu() - want).abs().max().item()
+    assert err < 6e-5, err
+    exact = ops.gemm_nt(D(a), D(w), bias=D(bias), residual=D(res))
+    assert (exact.double().cpu() - want).abs().max().item() < err * 2 + 1e-5  # sanity: fp32 path at least comparable
