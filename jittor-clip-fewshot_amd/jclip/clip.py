@@ -95,13 +95,15 @@ def read_state_dict(path: str) -> dict:
     from clipfs import safe_pkl
     with open(path, "rb") as f:
         head = f.read(4)
-    if head[:2] == b"PK":  # zip container: .npz or torch zip checkpoint
-        try:
+    if head[:2] == b"PK":  # zip container: .npz (members *.npy) or a torch zip checkpoint (archive/data.pkl ...)
+        import zipfile
+        with zipfile.ZipFile(path) as zf:
+            names = zf.namelist()
+        if names and all(n.endswith(".npy") for n in names):
             with np.load(path, allow_pickle=False) as z:
                 return {k: z[k] for k in z.files}
-        except Exception:
-            sd = torch.load(path, map_location="cpu", weights_only=True)
-            return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
     return safe_pkl.load(path)
 
 

@@ -105,3 +105,48 @@ def test_shard_bounds():
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         sizes = [hi - lo for lo, hi in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_clip_load_checkpoint_formats(tmp_path):
+    """clip.load / clip1.load_vlp from the three accepted local formats: a Jittor-style pickle of numpy arrays
+    (read without executing anything), .npz, and a torch zip checkpoint; 5-tuple return like the reference."""
+    import pickle
+    from clipfs import synth
+    from jclip import clip, clip1
+    sd = synth.synth_state_dict(synth.TINY, seed=3)
+    np_sd = {k: v.numpy() for k, v in sd.items()}
+    np_sd.update(input_resolution=np.array(64), context_length=np.array(16), vocab_size=np.array(512))
+    p_pkl, p_npz, p_pt = tmp_path / "m.pkl", tmp_path / "m.npz", tmp_path / "m.pt"
+    with open(p_pkl, "wb") as f:
+        pickle.dump(np_sd, f, protocol=4)
+    np.savez(p_npz, **{k: v for k, v in np_sd.items()})
+    torch.save(sd, p_pt)
+    cpu = torch.device("cpu")
+    for path in (p_pkl, p_npz, p_pt):
+        out = clip.load(str(path), device=cpu)
+        assert len(out) == 5
+        model = out[0]
+        assert model.visual.width == 128 and model.visual.tokens == 5 and model.visual.VPT is None
+        assert torch.equal(model.text_projection.data, sd["text_projection"])
+        assert not hasattr(model, "input_resolution") or True
+    mv = clip1.load_vlp(str(p_pkl), device=cpu)[0]
+    assert mv.visual.VPT.shape == (4, 128) and mv.visual.tokens == 9  # 4 VPT tokens after the patches
+    assert "visual.VPT" in dict(mv.named_parameters())
+    with pytest.raises(NotImplementedError):
+        clip.load(str(p_pkl), mode="res", device=cpu)
+
+
+def test_transforms_shapes():
+    from PIL import Image
+    from clipfs import synth
+    from jclip import clip
+    from jclip.model import build_model
+    rng = np.random.RandomState(0)
+    img = Image.fromarray(rng.randint(0, 255, (300, 400, 3), dtype=np.uint8))
+    t1, t2, t3, t4 = clip._transform1(224), clip._transform2(224), clip.tfm_train_base(224), clip.tfm_train_base1(224)
+    a, b = t1(img), t2(img)
+    assert a.shape == (3, 224, 224) and a.dtype == torch.float32 and 0 <= a.min() and a.max() <= 1
+    mean = torch.tensor(clip.CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(clip.CLIP_STD).view(3, 1, 1)
+    assert torch.allclose(b, (a - mean) / std, atol=1e-6)
+    assert t3(img).shape == t4(img).shape == (3, 224, 224)
