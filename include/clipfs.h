@@ -116,10 +116,16 @@ int clipfs_layernorm_bwd(const float* dy, const float* x, int ldx, const float* 
  * Replaces scaled_dot_product_attention + reshapes + permute(2,0,1,3):
  * jclip/mha.py:55-83,439-458 and lora_train_vlp.py:339-367,492-501.
  * Scores/probabilities never leave the CU (reference: [N*H,L,L] round trip in HBM). */
-int clipfs_attention_fwd(const float* qkv, float* out, int batch, int seq, int heads, int causal, void* stream);
-/* dqkv from dout, recomputing the probabilities from qkv. */
-int clipfs_attention_bwd(const float* qkv, const float* dout, float* dqkv, int batch, int seq, int heads,
-                         int causal, void* stream);
+int clipfs_attention_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal,
+                         void* stream);
+/* dqkv from dout, recomputing the probabilities from qkv.
+ * seq <= 96: register/LDS-resident kernels; out, lse and work may be NULL.
+ * seq  > 96 (ViT-L/14: 257): streaming kernels with an online softmax; the forward must have been given
+ * lse [clipfs_attention_lse_floats] (log-sum-exp of the scaled scores per (batch, head, query)), the backward
+ * needs the forward's `out`, that `lse` and a `work` buffer of the same size. */
+int clipfs_attention_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv,
+                         float* work, int batch, int seq, int heads, int causal, void* stream);
+size_t clipfs_attention_lse_floats(int batch, int seq, int heads);
 
 /* ------------------------------------------------------------------ LoRA --
  * t[m, s*r + j] = sum_k drop_s(x)[m,k] * A[s*r + j, k]       (the "down" half of

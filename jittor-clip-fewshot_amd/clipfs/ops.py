@@ -121,17 +121,21 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, *, ldx=None, dres=None, dx=None, ldd
     return dx
 
 
-def attention_fwd(qkv, batch, seq, heads, causal):
+def attention_fwd(qkv, batch, seq, heads, causal, want_lse=False):
     out = torch.empty(batch * seq, heads * 64, device=qkv.device, dtype=torch.float32)
-    check(_lib.load().clipfs_attention_fwd(_p(_f32(qkv)), _p(out), batch, seq, heads, int(causal), _stream()),
+    lib = _lib.load()
+    n = lib.clipfs_attention_lse_floats(batch, seq, heads) if want_lse else 0
+    lse = torch.empty(n, device=qkv.device, dtype=torch.float32) if n else None
+    check(lib.clipfs_attention_fwd(_p(_f32(qkv)), _p(out), _p(lse), batch, seq, heads, int(causal), _stream()),
           "attention_fwd")
-    return out
+    return (out, lse) if want_lse else out
 
 
-def attention_bwd(qkv, dout, batch, seq, heads, causal):
+def attention_bwd(qkv, dout, batch, seq, heads, causal, out=None, lse=None):
     dqkv = torch.empty_like(qkv)
-    check(_lib.load().clipfs_attention_bwd(_p(_f32(qkv)), _p(_f32(dout)), _p(dqkv), batch, seq, heads, int(causal),
-                                           _stream()), "attention_bwd")
+    work = torch.empty_like(lse) if lse is not None else None
+    check(_lib.load().clipfs_attention_bwd(_p(_f32(qkv)), _p(_f32(dout)), _p(out), _p(lse), _p(dqkv), _p(work), batch,
+                                           seq, heads, int(causal), _stream()), "attention_bwd")
     return dqkv
 
 

@@ -316,6 +316,163 @@ __global__ __launch_bounds__(512) void attention_bwd_kernel(const float* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Long sequences (ViT-L/14: L = 257): K/V no longer fit next to a wave's registers, so these kernels stream key
+// (or query) blocks of 64 from L2 with an online softmax -- one wave per query row (forward, dQ) or per key row
+// (dK, dV).  Correct for any L; not tuned (the B/32 path never takes them).  lse[(b*H + h)*L + i] =
+// max_i + log(sum_i) of the scaled scores is written by the forward and reused by the backward.
+// ---------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float dot64_row(const f32x4 (&u)[HD / 4], const float* __restrict__ row) {
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    const f32x4 k = *reinterpret_cast<const f32x4*>(row + 4 * c);
+    a0 = fmaf(u[c][0], k[0], a0);
+    a1 = fmaf(u[c][1], k[1], a1);
+    a0 = fmaf(u[c][2], k[2], a0);
+    a1 = fmaf(u[c][3], k[3], a1);
+  }
+  return a0 + a1;
+}
+
+// acc[lane] += sum_{t < n} vec[t] * base[(j0 + t) * ld + lane]   (vec: the wave's LDS row of 64 broadcast values)
+__device__ __forceinline__ float axpy_block(const float* __restrict__ vec, const float* __restrict__ base, size_t ld,
+                                            int lane, int n, float acc) {
+  for (int t = 0; t < n; t += 4) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(vec + t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (t + e < n) acc = fmaf(p[e], base[(size_t)(t + e) * ld + lane], acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void attention_generic_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                    float* __restrict__ lse, int L, int H, int causal) {
+  __shared__ __attribute__((aligned(16))) float sP[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int i = blockIdx.y * 4 + wave;
+  if (i >= L) return;
+  const int d = H * HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
+  f32x4 q[HD / 4];
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) q[c] = *reinterpret_cast<const f32x4*>(q0 + (size_t)i * ld + 4 * c);
+  float m = -INFINITY, l = 0.f, o = 0.f;
+  const int jend = causal ? i + 1 : L;
+  for (int j0 = 0; j0 < jend; j0 += 64) {
+    const int j = j0 + lane;
+    float s = -INFINITY;
+    if (j < jend) s = dot64_row(q, q0 + d + (size_t)j * ld) * 0.125f;
+    const float mn = fmaxf(m, wave_max(s));
+    const float pj = __expf(s - mn);  // 0 for masked lanes
+    const float f = __expf(m - mn);   // 0 on the first block (m = -inf)
+    l = l * f + wave_sum(pj);
+    sP[wave][lane] = pj;
+    __builtin_amdgcn_wave_barrier();
+    o = axpy_block(sP[wave], q0 + 2 * d + (size_t)j0 * ld, ld, lane, min(64, jend - j0), o * f);
+    __builtin_amdgcn_wave_barrier();
+    m = mn;
+  }
+  out[((size_t)b * L + i) * d + h * HD + lane] = o / l;
+  if (lse && lane == 0) lse[((size_t)b * H + h) * L + i] = m + __logf(l);
+}
+
+// dQ and D_i = dO_i . O_i   (one wave per query row)
+__global__ __launch_bounds__(256) void attention_generic_bwd_q_kernel(const float* __restrict__ qkv,
+                                                                      const float* __restrict__ dout,
+                                                                      const float* __restrict__ out,
+                                                                      const float* __restrict__ lse,
+                                                                      float* __restrict__ dqkv, float* __restrict__ Dbuf,
+                                                                      int L, int H, int causal) {
+  __shared__ __attribute__((aligned(16))) float sP[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int i = blockIdx.y * 4 + wave;
+  if (i >= L) return;
+  const int d = H * HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
+  const float* do_i = dout + ((size_t)b * L + i) * d + h * HD;
+  f32x4 q[HD / 4], g[HD / 4];
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    q[c] = *reinterpret_cast<const f32x4*>(q0 + (size_t)i * ld + 4 * c);
+    g[c] = *reinterpret_cast<const f32x4*>(do_i + 4 * c);
+  }
+  const float Di = wave_sum(do_i[lane] * out[((size_t)b * L + i) * d + h * HD + lane]);
+  const float li = lse[((size_t)b * H + h) * L + i];
+  if (lane == 0) Dbuf[((size_t)b * H + h) * L + i] = Di;
+  float acc = 0.f;
+  const int jend = causal ? i + 1 : L;
+  for (int j0 = 0; j0 < jend; j0 += 64) {
+    const int j = j0 + lane;
+    float ds = 0.f;
+    if (j < jend) {
+      const float pj = __expf(dot64_row(q, q0 + d + (size_t)j * ld) * 0.125f - li);
+      const float dp = dot64_row(g, q0 + 2 * d + (size_t)j * ld);
+      ds = pj * (dp - Di) * 0.125f;
+    }
+    sP[wave][lane] = ds;
+    __builtin_amdgcn_wave_barrier();
+    acc = axpy_block(sP[wave], q0 + d + (size_t)j0 * ld, ld, lane, min(64, jend - j0), acc);
+    __builtin_amdgcn_wave_barrier();
+  }
+  dqkv[((size_t)b * L + i) * ld + h * HD + lane] = acc;
+}
+
+// dK and dV   (one wave per key row; queries streamed in blocks of 64, lane = query)
+__global__ __launch_bounds__(256) void attention_generic_bwd_kv_kernel(const float* __restrict__ qkv,
+                                                                       const float* __restrict__ dout,
+                                                                       const float* __restrict__ lse,
+                                                                       const float* __restrict__ Dbuf,
+                                                                       float* __restrict__ dqkv, int L, int H, int causal) {
+  __shared__ __attribute__((aligned(16))) float sP[4][64];
+  __shared__ __attribute__((aligned(16))) float sS[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int j = blockIdx.y * 4 + wave;
+  if (j >= L) return;
+  const int d = H * HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
+  const float* do0 = dout + (size_t)b * L * d + (size_t)h * HD;
+  f32x4 k[HD / 4], v[HD / 4];
+#pragma unroll
+  for (int c = 0; c < HD / 4; ++c) {
+    k[c] = *reinterpret_cast<const f32x4*>(q0 + d + (size_t)j * ld + 4 * c);
+    v[c] = *reinterpret_cast<const f32x4*>(q0 + 2 * d + (size_t)j * ld + 4 * c);
+  }
+  float av = 0.f, ak = 0.f;
+  const int ibeg = causal ? j : 0;  // P_ij = 0 for i < j
+  for (int i0 = ibeg & ~63; i0 < L; i0 += 64) {
+    const int i = i0 + lane;
+    float pj = 0.f, ds = 0.f;
+    if (i < L && i >= ibeg) {
+      const size_t st = ((size_t)b * H + h) * L + i;
+      pj = __expf(dot64_row(k, q0 + (size_t)i * ld) * 0.125f - lse[st]);
+      const float dp = dot64_row(v, do0 + (size_t)i * d);
+      ds = pj * (dp - Dbuf[st]) * 0.125f;
+    }
+    sP[wave][lane] = pj;
+    sS[wave][lane] = ds;
+    __builtin_amdgcn_wave_barrier();
+    const int n = min(64, L - i0);
+    av = axpy_block(sP[wave], do0 + (size_t)i0 * d, (size_t)d, lane, n, av);
+    ak = axpy_block(sS[wave], q0 + (size_t)i0 * ld, ld, lane, n, ak);
+    __builtin_amdgcn_wave_barrier();
+  }
+  dqkv[((size_t)b * L + j) * ld + 2 * d + h * HD + lane] = av;
+  dqkv[((size_t)b * L + j) * ld + d + h * HD + lane] = ak;
+}
+
 static int check_attn(const char* what, int batch, int seq, int heads, int max_seq) {
   CLIPFS_REQUIRE(batch > 0 && heads > 0 && seq > 0 && seq <= max_seq, "%s: batch %d seq %d heads %d unsupported (seq <= %d)",
                  what, batch, seq, heads, max_seq);
@@ -334,13 +491,21 @@ static int padded_lp(int seq) {
 
 using namespace clipfs;
 
-extern "C" int clipfs_attention_fwd(const float* qkv, float* out, int batch, int seq, int heads, int causal,
+constexpr int ATTN_FAST_MAX = 96;   // register/LDS-resident kernels up to here (forward-only inference: 128)
+constexpr int ATTN_MAX_SEQ = 4096;
+
+extern "C" int clipfs_attention_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal,
                                     void* stream) {
-  CLIPFS_CHECK(check_attn("attention_fwd", batch, seq, heads, 128));
+  CLIPFS_CHECK(check_attn("attention_fwd", batch, seq, heads, ATTN_MAX_SEQ));
   CLIPFS_REQUIRE(qkv && out && aligned16(qkv), "attention_fwd: null or misaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (seq > 128 || (seq > ATTN_FAST_MAX && lse)) {
+    hipLaunchKernelGGL(attention_generic_fwd_kernel, dim3(batch * heads, (seq + 3) / 4), dim3(256), 0, st, qkv, out, lse,
+                       seq, heads, causal);
+    return launch_status();
+  }
   static const int thr_cfg = getenv("CLIPFS_ATTN_FWD_THREADS") ? atoi(getenv("CLIPFS_ATTN_FWD_THREADS")) : 0;
   const dim3 grid(batch * heads), block(thr_cfg ? thr_cfg : 256);
-  hipStream_t st = (hipStream_t)stream;
   const size_t lds1 = ((size_t)seq * KSTRIDE + 16 * 64) * sizeof(float);
   const size_t lds2 = ((size_t)seq * KSTRIDE + 16 * 128) * sizeof(float);
   if (seq <= 64)
@@ -354,11 +519,22 @@ extern "C" int clipfs_attention_fwd(const float* qkv, float* out, int batch, int
   return launch_status();
 }
 
-extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, float* dqkv, int batch, int seq, int heads,
-                                    int causal, void* stream) {
-  // C1 keeps two columns of length LMAX in VGPRs: 2 * 96 is the most that fits without spilling
-  CLIPFS_CHECK(check_attn("attention_bwd", batch, seq, heads, 96));
+extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv,
+                                    float* work, int batch, int seq, int heads, int causal, void* stream) {
+  CLIPFS_CHECK(check_attn("attention_bwd", batch, seq, heads, ATTN_MAX_SEQ));
   CLIPFS_REQUIRE(qkv && dout && dqkv && aligned16(qkv) && aligned16(dout), "attention_bwd: null or misaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (seq > ATTN_FAST_MAX) {
+    CLIPFS_REQUIRE(out && lse && work, "attention_bwd: seq %d > %d needs the forward's out and lse and a work buffer", seq,
+                   ATTN_FAST_MAX);
+    const dim3 grid(batch * heads, (seq + 3) / 4);
+    hipLaunchKernelGGL(attention_generic_bwd_q_kernel, grid, dim3(256), 0, st, qkv, dout, out, lse, dqkv, work, seq, heads,
+                       causal);
+    CLIPFS_CHECK(launch_status());
+    hipLaunchKernelGGL(attention_generic_bwd_kv_kernel, grid, dim3(256), 0, st, qkv, dout, lse, work, dqkv, seq, heads,
+                       causal);
+    return launch_status();
+  }
   const int lp = padded_lp(seq);
   // P^T, dS^T, and dS (whose storage first serves as the [seq][KSTRIDE] K/V staging buffer) + 16 floats overhang
   const size_t third = (size_t)seq * (lp > KSTRIDE ? lp : KSTRIDE);
@@ -366,7 +542,6 @@ extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, float* 
   CLIPFS_REQUIRE(lds <= 160 * 1024, "attention_bwd: seq %d needs %zu bytes of LDS (> 160 KiB)", seq, lds);
   static const int thr_cfg = getenv("CLIPFS_ATTN_BWD_THREADS") ? atoi(getenv("CLIPFS_ATTN_BWD_THREADS")) : 0;
   const dim3 grid(batch * heads), block(thr_cfg ? thr_cfg : (seq > 64 ? 512 : 256));
-  hipStream_t st = (hipStream_t)stream;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_bwd_kernel<64>),
@@ -384,4 +559,8 @@ extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, float* 
   else
     hipLaunchKernelGGL((attention_bwd_kernel<96>), grid, block, lds, st, qkv, dout, dqkv, seq, heads, causal, lp);
   return launch_status();
+}
+
+extern "C" size_t clipfs_attention_lse_floats(int batch, int seq, int heads) {
+  return seq > ATTN_FAST_MAX ? (size_t)batch * heads * seq : 0;
 }

@@ -13,7 +13,7 @@ namespace clipfs {
 static inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 struct SavedLayout {
-  size_t x_in, stat1, h1, t_qkv, qkv, att, t_o, x_mid, stat2, u, total;
+  size_t x_in, stat1, h1, t_qkv, qkv, att, lse, t_o, x_mid, stat2, u, total;
 };
 
 static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
@@ -26,6 +26,7 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
   L.t_qkv = o; o += al4(M * 3 * r);
   L.qkv = o;   o += al4(M * 3 * d);
   L.att = o;   o += al4(M * d);
+  L.lse = o;   o += al4(clipfs_attention_lse_floats((int)(M / t->seq), t->seq, t->heads));  // 0 for seq <= 96
   L.t_o = o;   o += al4(M * r);
   L.x_mid = o; o += al4(M * d);
   L.stat2 = o; o += al4(2 * M);
@@ -137,7 +138,7 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
       CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, st));
     CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
                       b.lora_b_qkv, r, 3, d, t->lora_scale, st));
-    CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, batch, t->seq, t->heads, t->causal, st));
+    CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
     if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, st));
     CLIPFS_CHECK(gemm(att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
                       1, d, t->lora_scale, st));
@@ -192,7 +193,9 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
       CLIPFS_CHECK(clipfs_lora_bwd(dx, sv + SL.att, sv + SL.t_o, b.lora_a_o, b.lora_b_o, dt, b.g_lora_a_o, b.g_lora_b_o,
                                    datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, work, st));
     }
-    CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, dqkv, batch, t->seq, t->heads, t->causal, st));
+    // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
+    CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
+                                      t->causal, st));
     const bool need_dx = !(l == 0 && stop_at_input);
     if (need_dx)
       CLIPFS_CHECK(gemm(dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,

@@ -45,7 +45,7 @@ def test_argument_errors_do_not_touch_the_gpu():
     rc = lib.clipfs_layernorm_fwd(None, 0, None, None, None, None, None, 4, 7, 1e-5, None)
     assert rc == 1
     assert b"width" in lib.clipfs_last_error()
-    rc = lib.clipfs_attention_fwd(None, None, 1, 500, 2, 0, None)
+    rc = lib.clipfs_attention_fwd(None, None, None, 1, 5000, 2, 0, None)
     assert rc == 1 and b"seq" in lib.clipfs_last_error()
     assert lib.clipfs_gemm_nt(None, None) == 1
     with pytest.raises(_lib.ClipfsError):

@@ -388,3 +388,46 @@ def test_bf16x3_precision_mode(dev, monkeypatch):
     assert torch.equal(L.ops.topk(res["bf16x3"][0].float().to(dev), 5).cpu().long(), O.jt_topk(wl.float(), 5))
     g32, g16 = res["fp32"][1], res["bf16x3"][1]
     assert (g32 - g16).abs().max() < 3e-3 * g32.abs().max()
+
+
+def test_vit_l14_shapes(dev, monkeypatch):
+    """cfg-5 shapes (ViT-L/14: width 1024, 16 heads, patch 14 -> L = 257, text width 768, embed 768, LoRA r = 16),
+    depth cut to 2 + 2 blocks: forward logits and a full train step vs the fp64 oracle.  Computed in fp32 (the
+    reference's cfg-5 is fp16 storage: not built yet); exercises the generic im2col path, the long-sequence
+    attention kernels and the rank-16 adapter kernels."""
+    import dataclasses
+    import lora_train_vlp as L
+    from clipfs import synth
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(synth.VIT_L14, vision_layers=2, transformer_layers=2, vocab_size=2048)
+    assert cfg.vision_tokens == 257 and cfg.vision_heads == 16 and cfg.transformer_heads == 12
+    sd, model = _build(cfg, dev, seed=17)
+    args = _args("ViT-L/14", r=16)
+    lw = synth.synth_lora(cfg, 16, seed=5)
+    layers = _apply(model, cfg, args, lw, monkeypatch)
+    assert layers[0].scaling == 0.25  # alpha / sqrt(16)
+    B, Cn = 3, 5
+    img = synth.synth_images(B, 224, seed=3)
+    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=4, max_len=20)
+    tgt = synth.synth_labels(B, Cn, seed=2)
+    model.eval()
+    tr = L.LoRATrainer(model)
+    tr.flat.zero_grad()
+    loss_sum, _, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    tl, vl = _oracle_lora(lw, cfg, requires_grad=True)
+    loss, wl = O.train_step_loss(sd64, img.double(), cap, tgt, tl, vl, 0.25, text_chunk=Cn)
+    loss.backward()
+    assert _err(logits, wl) < 1e-3
+    assert abs(loss_sum.item() / B - loss.item()) < 1e-4
+    names = {"q": "q_proj", "k": "k_proj", "v": "v_proj"}
+    blks = list(tl.values()) + list(vl.values())
+    gmax = max(t.grad.abs().max().item() for blk in blks for ab in blk.values() for t in ab.values())
+    worst = 0.0
+    for i, layer in enumerate(layers):
+        pairs = dict((id(prm), g) for prm, g in layer.trainable_pairs())
+        for pr in "qkv":
+            m = getattr(layer, names[pr])
+            for nm, prm in (("w_lora_A", m.w_lora_A), ("w_lora_B", m.w_lora_B)):
+                worst = max(worst, _err(pairs[id(prm)], blks[i][names[pr]][nm].grad))
+    assert worst < 1e-4 * max(gmax, 1e-3), (worst, gmax)

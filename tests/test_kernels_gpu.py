@@ -128,7 +128,8 @@ def test_layernorm_strided_rows(dev):
 
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,L,H,causal", [(3, 50, 2, False), (2, 54, 12, False), (3, 77, 8, True), (2, 16, 1, True),
-                                          (1, 5, 2, False), (2, 96, 2, True)])
+                                          (1, 5, 2, False), (2, 96, 2, True), (2, 257, 2, False), (1, 130, 1, True),
+                                          (1, 100, 2, False)])
 def test_attention(dev, B, L, H, causal):
     from clipfs import ops
     from oracle import clip_oracle as O
@@ -138,11 +139,13 @@ def test_attention(dev, B, L, H, causal):
     mask = O.build_causal_mask(L, torch.float64) if causal else None
     o = O.sdpa(q, k, v, mask).permute(0, 2, 1, 3).reshape(B * L, d)
     qd = qkv.detach().float().to(dev)
-    got = ops.attention_fwd(qd, B, L, H, causal)
+    got, lse = ops.attention_fwd(qd, B, L, H, causal, want_lse=True)  # lse is None on the short-sequence kernels
+    assert (lse is not None) == (L > 96)
     _close(got, o, 2e-5, "attention fwd")
+    _close(ops.attention_fwd(qd, B, L, H, causal), o, 2e-5, "attention fwd (inference)")
     do = _rand(B * L, d, seed=2)
     o.backward(do)
-    dq = ops.attention_bwd(qd, do.float().to(dev), B, L, H, causal)
+    dq = ops.attention_bwd(qd, do.float().to(dev), B, L, H, causal, out=got, lse=lse)
     _close(dq, qkv.grad, 5e-5, "attention bwd")
 
 
