@@ -213,6 +213,16 @@ size_t clipfs_mta_work_floats(int n_img, int views, int width, int classes);
 int clipfs_mta(const float* feats, const float* text, float* mode_out, float* logits_out, float* work,
                int n_img, int views, int width, int classes, void* stream);
 
+/* ----------------------------------------------------------- TTA views --
+ * One kernel writes every normalised fp32 view [n_views, 3, S, S] of one uint8 HWC source image resident in HBM:
+ * crop -> PIL-exact 8-bit resize (bilinear or bicubic, Pillow Resample.c restated) -> S x S window -> optional
+ * horizontal flip -> (u8 - 255 mean) / (255 std).  Replaces the CPU/PIL view generation of ood.py:946-958,1084-1089
+ * and jclip/clip.py:130-144 (Resize 256 bicubic + CenterCrop; RandomResizedCrop bilinear + RandomHorizontalFlip).
+ * recs: int32 [n_views, 10] = {top, left, h, w, flip, out_w, out_h, win_x, win_y, filter(0 bilinear, 1 bicubic)};
+ * boxes are sampled on the host (clipfs/views.py).  Needs max(h/out_h, w/out_w) * support * 2 + 1 <= 24 taps. */
+int clipfs_tta_views(const uint8_t* image, int height, int width, const int32_t* recs, int n_views, int out_size,
+                     const float* mean, const float* stdv, float* out, void* stream);
+
 /* --------------------------------------------------------- tower drivers --
  * C++ sequencing of the kernels above for one transformer tower, so that one call
  * from Python enqueues a whole forward or backward (no per-kernel interpreter cost).

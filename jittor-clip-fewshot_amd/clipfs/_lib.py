@@ -96,6 +96,7 @@ SIGNATURES = {
     "clipfs_adamw": (_i, [_p, _p, _p, _p, _sz, _i, _f, _f, _f, _f, _f, _f, _p]),
     "clipfs_mta_work_floats": (_sz, [_i, _i, _i, _i]),
     "clipfs_mta": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "clipfs_tta_views": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p]),
     "clipfs_tower_saved_floats": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_scratch_floats": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_fwd": (_i, [C.POINTER(Tower), _p, _i, _p, _p, _p]),

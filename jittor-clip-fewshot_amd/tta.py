@@ -10,6 +10,25 @@ import torch
 from clipfs import ops
 
 
+def make_tta_views(image, n_crops: int = 512, scale=(0.5, 1.0), seed: int = 0, size: int = 224, device=None):
+    """The 1 + n_crops views of one image as a device tensor [1 + n_crops, 3, size, size] (view 0 = the centre
+    preprocess, the rest RandomResizedCrop(scale) + flip), generated ON THE GPU from the uint8 image
+    (csrc/views.hip, pixel-exact with PIL).  Replaces the reference's CPU worker loop ood.py:946-958 /
+    lora_train_vlp.py:1065-1077.  ``image``: PIL image, uint8 numpy [H, W, 3] or uint8 tensor."""
+    import numpy as np
+    from clipfs import views
+    if hasattr(image, "convert"):
+        image = np.asarray(image.convert("RGB"))
+    if isinstance(image, np.ndarray):
+        image = torch.from_numpy(np.ascontiguousarray(image))
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    image = image.to(device)
+    H, W = image.shape[:2]
+    recs = views.view_records(W, H, n_crops, scale=scale, seed=seed, size=size)
+    return views.make_views(image, recs, size)
+
+
 @torch.no_grad()
 def fuse_top5(cos: torch.Tensor, cos1: torch.Tensor, cos3: torch.Tensor,
               head_logits: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
