@@ -196,6 +196,10 @@ int clipfs_topk(const float* logits, int32_t* labels, int rows, int classes, int
 int clipfs_channel_affine(const float* x, const float* scale1, const float* bias1, float* y, int rows,
                           int width, void* stream);
 int clipfs_logit_normalize(const float* z, float* out, float* work, int rows, int classes, void* stream);
+/* backward of logit_normalize (head training, slow_pace.py:1671-1675): dz from dzn, statistics recomputed from z */
+int clipfs_logit_normalize_bwd(const float* z, const float* dzn, float* dz, int rows, int classes, void* stream);
+/* out[c] = sum_r x[r,c] * (y ? y[r,c] : 1): bias / per-channel scale gradients of the head (fixed row order) */
+int clipfs_colsum(const float* x, const float* y, float* out, int rows, int cols, void* stream);
 
 /* ------------------------------------------------------------- optimiser --
  * jittor.optim.AdamW.step (lora_train_vlp.py:946,1002): p *= 1 - lr*wd; m,v update;

@@ -93,6 +93,8 @@ SIGNATURES = {
     "clipfs_topk": (_i, [_p, _p, _i, _i, _i, _p]),
     "clipfs_channel_affine": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "clipfs_logit_normalize": (_i, [_p, _p, _p, _i, _i, _p]),
+    "clipfs_logit_normalize_bwd": (_i, [_p, _p, _p, _i, _i, _p]),
+    "clipfs_colsum": (_i, [_p, _p, _p, _i, _i, _p]),
     "clipfs_adamw": (_i, [_p, _p, _p, _p, _sz, _i, _f, _f, _f, _f, _f, _f, _p]),
     "clipfs_mta_work_floats": (_sz, [_i, _i, _i, _i]),
     "clipfs_mta": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

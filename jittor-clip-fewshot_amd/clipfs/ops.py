@@ -277,6 +277,19 @@ def logit_normalize(z):
     return out
 
 
+def logit_normalize_bwd(z, dzn):
+    dz = torch.empty_like(z)
+    check(_lib.load().clipfs_logit_normalize_bwd(_p(_f32(z)), _p(_f32(dzn)), _p(dz), z.shape[0], z.shape[1], _stream()),
+          "logit_normalize_bwd")
+    return dz
+
+
+def colsum(x, y=None):
+    out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    check(_lib.load().clipfs_colsum(_p(_f32(x)), _p(y), _p(out), x.shape[0], x.shape[1], _stream()), "colsum")
+    return out
+
+
 def adamw(p, g, m, v, step, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
     check(_lib.load().clipfs_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), step, lr, betas[0], betas[1], eps,
                                    weight_decay, grad_scale, _stream()), "adamw")

@@ -351,6 +351,69 @@ __global__ __launch_bounds__(1024) void logit_normalize_kernel(const float* __re
   }
 }
 
+// backward of logit_normalize: zn = (z - rowmean(z)) / sigma, sigma = sqrt(max(sum((z - mean_all)^2)/(n-1), 1e-6))
+//   dz = (dzn - rowmean(dzn)) / sigma  -  (sum(dzn * zn) / sigma) * (z - mean_all) / ((n - 1) * sigma)   [2nd term 0 if clamped]
+__global__ __launch_bounds__(1024) void logit_normalize_bwd_kernel(const float* __restrict__ z,
+                                                                   const float* __restrict__ dzn, float* __restrict__ dz,
+                                                                   int rows, int classes) {
+  __shared__ float red[16];
+  __shared__ float stat[3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t n = (size_t)rows * classes;
+  auto block_total = [&](float v) -> float {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+  };
+  float s = 0.f;
+  for (size_t i = tid; i < n; i += 1024) s += z[i];
+  const float mean = block_total(s) / (float)n;
+  float q = 0.f;
+  for (size_t i = tid; i < n; i += 1024) {
+    const float d = z[i] - mean;
+    q = fmaf(d, d, q);
+  }
+  const float var = block_total(q) / (float)(n - 1);
+  const bool clamped = var < 1e-6f;
+  const float sd = sqrtf(fmaxf(var, 1e-6f));
+  // g = sum_ij dzn_ij * (z_ij - rowmean_i) ; needs the row means first: each wave owns rows r = wave, wave+16, ...
+  float g = 0.f;
+  for (int r = wave; r < rows; r += 16) {
+    float rs = 0.f;
+    for (int c = lane; c < classes; c += 64) rs += z[(size_t)r * classes + c];
+    const float rm = wave_sum(rs) / (float)classes;
+    for (int c = lane; c < classes; c += 64) g = fmaf(dzn[(size_t)r * classes + c], z[(size_t)r * classes + c] - rm, g);
+  }
+  g = block_total(g);  // = sigma * sum(dzn * zn)
+  const float coef = clamped ? 0.f : g / (sd * sd * sd * (float)(n - 1));
+  for (int r = wave; r < rows; r += 16) {
+    float ds = 0.f;
+    for (int c = lane; c < classes; c += 64) ds += dzn[(size_t)r * classes + c];
+    const float dm = wave_sum(ds) / (float)classes;
+    for (int c = lane; c < classes; c += 64) {
+      const size_t i = (size_t)r * classes + c;
+      dz[i] = (dzn[i] - dm) / sd - coef * (z[i] - mean);
+    }
+  }
+}
+
+// out[c] (+)= sum_r x[r,c] * (y ? y[r,c] : 1)     one thread per column, fixed row order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     float* __restrict__ out, int rows, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    const float v = x[(size_t)r * cols + c];
+    acc = y ? fmaf(v, y[(size_t)r * cols + c], acc) : acc + v;
+  }
+  out[c] = acc;
+}
+
 // ---- AdamW over the flat trainable buffer (lora_train_vlp.py:946,1002) ----
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
@@ -491,6 +554,19 @@ extern "C" int clipfs_channel_affine(const float* x, const float* scale1, const 
 extern "C" int clipfs_logit_normalize(const float* z, float* out, float* work, int rows, int classes, void* stream) {
   CLIPFS_REQUIRE(z && out && rows > 0 && classes > 0 && (size_t)rows * classes > 1, "logit_normalize: bad args");
   hipLaunchKernelGGL(logit_normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, out, work, rows, classes);
+  return launch_status();
+}
+
+extern "C" int clipfs_logit_normalize_bwd(const float* z, const float* dzn, float* dz, int rows, int classes,
+                                          void* stream) {
+  CLIPFS_REQUIRE(z && dzn && dz && rows > 0 && classes > 0 && (size_t)rows * classes > 1, "logit_normalize_bwd: bad args");
+  hipLaunchKernelGGL(logit_normalize_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, z, dzn, dz, rows, classes);
+  return launch_status();
+}
+
+extern "C" int clipfs_colsum(const float* x, const float* y, float* out, int rows, int cols, void* stream) {
+  CLIPFS_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad args");
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, out, rows, cols);
   return launch_status();
 }
 

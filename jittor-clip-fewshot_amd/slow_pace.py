@@ -94,10 +94,48 @@ class TextEncoder(nn.Module):
     execute = forward
 
 
+class _ChannelLPFn(torch.autograd.Function):
+    """z = (scale1 * f + bias1) W^T + c with gradients for scale1, bias1, W, c (and f)."""
+
+    @staticmethod
+    def forward(ctx, f, scale1, bias1, w, c):
+        f = f.contiguous()
+        fp = ops.channel_affine(f, scale1.contiguous(), bias1.contiguous())
+        ctx.save_for_backward(f, fp, scale1, w)
+        return ops.gemm_nt(fp, w.contiguous(), bias=c.contiguous())
+
+    @staticmethod
+    def backward(ctx, dz):
+        f, fp, scale1, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        R, Cn = dz.shape
+        d = f.shape[1]
+        dw = ops.matmul_small(dz, fp, Cn, d, R, 1, Cn, d, 1)          # dW[c,k] = sum_r dz[r,c] f'[r,k]
+        dc = ops.colsum(dz)
+        dfp = ops.matmul_small(dz, w.contiguous(), R, d, Cn, Cn, 1, d, 1)  # df'[r,k] = sum_c dz[r,c] W[c,k]
+        ds = ops.colsum(dfp, f)
+        db = ops.colsum(dfp)
+        df = ops.channel_affine(dfp, scale1.contiguous(), torch.zeros_like(scale1)) if ctx.needs_input_grad[0] else None
+        return df, ds, db, dw, dc
+
+
+class _LogitNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        z = z.contiguous()
+        ctx.save_for_backward(z)
+        return ops.logit_normalize(z)
+
+    @staticmethod
+    def backward(ctx, dzn):
+        (z,) = ctx.saved_tensors
+        return ops.logit_normalize_bwd(z, dzn.contiguous())
+
+
 class Channel_LP(nn.Module):
-    """slow_pace.py:1195-1206: out = Linear_{512->403}(scale1 * f + bias1); ``fc.weight`` is initialised
-    from the zero-shot text features by the caller (:1537-1540).  Inference only on the HIP path
-    (head training is a stage-2 "next" item)."""
+    """slow_pace.py:1195-1206: out = Linear_{512->403}(scale1 * f + bias1); ``fc.weight`` is initialised from the
+    zero-shot text features by the caller (:1537-1540).  Differentiable with respect to scale1 / bias1 / fc (the
+    stage-2 head training, :1671-1675); forward and backward are HIP kernels."""
 
     def __init__(self, in_dim: int = 512, n_classes: int = 403, device=None):
         super().__init__()
@@ -107,19 +145,16 @@ class Channel_LP(nn.Module):
         fc = nn.Linear(in_dim, n_classes)
         self.fc = fc.to(device) if device is not None else fc
 
-    @torch.no_grad()
     def forward(self, features: torch.Tensor) -> torch.Tensor:
-        f = features.to(self.scale1.device, torch.float32).contiguous()
-        return ops.gemm_nt(ops.channel_affine(f, self.scale1.data, self.bias1.data), self.fc.weight.data.contiguous(),
-                           bias=self.fc.bias.data)
+        f = features.to(self.scale1.device, torch.float32)
+        return _ChannelLPFn.apply(f, self.scale1, self.bias1, self.fc.weight, self.fc.bias)
 
     execute = forward
 
 
-@torch.no_grad()
 def logit_normalize(logit: torch.Tensor) -> torch.Tensor:
-    """slow_pace.py:1276-1280."""
-    return ops.logit_normalize(logit.contiguous().float())
+    """slow_pace.py:1276-1280 (differentiable)."""
+    return _LogitNormFn.apply(logit.float())
 
 
 @torch.no_grad()

@@ -146,3 +146,31 @@ def test_clip_classifier_and_cls_acc(dev, b32):
     big[2, 5] = 1
     t2 = torch.tensor([3, 400, 390])
     assert ood.cls_acc(big.to(dev), t2) == O.cls_acc_ood(big, t2)
+
+
+def test_head_training_step(dev):
+    """Stage-2 head objective (slow_pace.py:1666-1675): CE(logit_normalize(Channel_LP(concat(img feats, text feats))),
+    concat(target, arange(C))) -- loss and gradients of scale1 / bias1 / fc.weight / fc.bias vs fp64 autograd."""
+    import slow_pace as SP
+    from clipfs import engine as E
+    from oracle import clip_oracle as O
+    g = torch.Generator().manual_seed(11)
+    Cn, d, B = 403, 512, 32
+    head = SP.Channel_LP(d, Cn, device=dev)
+    txt = O.l2_normalize(torch.randn(Cn, d, generator=g, dtype=torch.float64))
+    with torch.no_grad():
+        head.fc.weight.copy_(txt.float())                      # zero-shot text features (:1537-1540)
+        head.scale1.copy_(1 + 0.05 * torch.randn(d, generator=g))
+        head.bias1.copy_(0.05 * torch.randn(d, generator=g))
+    feats = torch.cat([torch.randn(B, d, generator=g) * 0.4, txt.float()], dim=0)   # raw image feats + text feats
+    target = torch.cat([torch.randint(0, 374, (B,), generator=g), torch.arange(Cn)])
+    out = SP.logit_normalize(head(feats.to(dev)))
+    loss = E.cross_entropy_loss(out, target.to(dev))
+    loss.backward()
+    p64 = [t.detach().double().cpu().requires_grad_() for t in (head.scale1, head.bias1, head.fc.weight, head.fc.bias)]
+    want = O.jt_cross_entropy(O.logit_normalize(O.channel_lp(feats.double(), *p64)), target)
+    want.backward()
+    assert abs(loss.item() - want.item()) < 1e-5
+    for mine, ref in zip((head.scale1, head.bias1, head.fc.weight, head.fc.bias), p64):
+        err = (mine.grad.double().cpu() - ref.grad).abs().max().item()
+        assert err < 1e-4 * max(ref.grad.abs().max().item(), 1e-3), err
