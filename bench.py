@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--serial-towers", action="store_true",
                     help="run the text and image towers back to back on one stream (default: text tower on a side stream)")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "fp16"], default="fp32",
                     help="GEMM arithmetic of the towers: exact fp32 MFMA (default) or split-bf16 x3 (opt-in fast mode)")
     ap.add_argument("--trim-text", action="store_true",
                     help="opt-in: skip the text positions after the batch's last EOT (dead under the causal mask); "
@@ -230,7 +230,7 @@ def main():
             "metric": "images/sec ViT-B/32 fwd+LoRA-bwd bs=256", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f32 (tower GEMMs as split-bf16 x3 MFMA, fp32 accumulate)", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16x3": "f32 (tower GEMMs as split-bf16 x3 MFMA, fp32 accumulate)", "fp16": "f16 operands in the tower GEMMs, fp32 accumulate"}[args.precision], "data": "synthetic",
             "config": {"workload": "cfg-2: ViT-B/32 + rank-4 LoRA(q,k,v; 12 text + 12 vision blocks; shipped "
                                    "lora_weights.pkl) + 4 text-prompt tokens; run_lora train step = text tower "
                                    "fwd+bwd on 403 captions + image tower fwd+bwd + 100*cos CE + AdamW"

@@ -75,8 +75,9 @@ typedef struct clipfs_gemm_args {
   float lora_scale;
   int a_mode;              /* 0 dense, 1 patch im2col */
   int img_res, patch, out_tokens; /* a_mode 1 */
-  const void* B_planes;    /* optional: B pre-split into bf16 hi/lo planes (clipfs_split_bf16): selects the
-                              split-bf16 x3 MFMA kernel (a_mode 0, K % 32 == 0, ldb == K); NULL = exact fp32 */
+  const void* B_planes;    /* optional 16-bit copy of B (a_mode 0, K % 32 == 0, ldb == K); NULL = exact fp32 */
+  int b_format;            /* 1: bf16 hi/lo planes (clipfs_split_bf16) -> split-bf16 x3 kernel;
+                              2: one f16 plane (clipfs_convert_f16) -> f16 MFMA kernel (cfg-5's fp16 path) */
   float* workspace;        /* optional split-K scratch (NULL: never split); see clipfs_gemm_workspace_floats */
   size_t workspace_floats;
 } clipfs_gemm_args;
@@ -89,6 +90,9 @@ int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
  * ("bf16 x 3") GEMM: a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
  * `planes` holds 2*n bf16 values (4*n bytes); n % 8 == 0. */
 int clipfs_split_bf16(const float* src, void* planes, size_t n, void* stream);
+/* dst[0..n) = f16(src): weights for the fp16 MFMA mode (v_mfma_f32_32x32x16_f16, fp32 accumulate; activations are
+ * rounded to f16 in the staging path).  Tolerance is that of fp16 products (~5e-4 relative), stated in the tests. */
+int clipfs_convert_f16(const float* src, void* dst, size_t n, void* stream);
 int clipfs_gemm_splits(int M, int N, int K);
 size_t clipfs_gemm_workspace_floats(int M, int N, int K);
 /* Diagnostics for bench.py's roofline leg (never enabled inside a timed region): while enabled, every
@@ -243,8 +247,9 @@ typedef struct clipfs_block {
   const float *lora_a_qkv, *lora_b_qkv, *lora_a_o, *lora_b_o;
   float *g_lora_a_qkv, *g_lora_b_qkv, *g_lora_a_o, *g_lora_b_o; /* gradient slots (accumulated into) */
   unsigned lora_mask;                   /* bit0 q, bit1 k, bit2 v, bit3 o */
-  /* optional bf16 hi/lo planes of the four weights and of their transposed copies (clipfs_split_bf16); when
-   * present the tower's GEMMs use the split-bf16 x3 kernel, otherwise the exact fp32 MFMA kernel */
+  /* optional 16-bit copies of the four weights and of their transposed copies (clipfs_split_bf16 /
+   * clipfs_convert_f16, format in clipfs_tower.weight_format); when present the tower's GEMMs use the
+   * bf16 x 3 or f16 MFMA kernel, otherwise the exact fp32 MFMA kernel */
   const void *w_qkv_p, *w_o_p, *w_fc_p, *w_pr_p, *w_qkv_t_p, *w_o_t_p, *w_fc_t_p, *w_pr_t_p;
 } clipfs_block;
 
@@ -255,6 +260,7 @@ typedef struct clipfs_tower {
   uint64_t dropout_seed;    /* 0 = no dropout (eval) */
   uint32_t dropout_stream0; /* stream id of layer 0 segment 0; layer l uses stream0 + 4*l + s */
   const clipfs_block* blocks; /* HOST array [layers] of device pointers */
+  int weight_format;        /* format of the blocks' *_p copies: 0 none (exact fp32), 1 bf16 hi/lo, 2 f16 */
 } clipfs_tower;
 
 /* floats needed per tower call for saved activations / scratch */

@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
         ("lora_r", C.c_int), ("lora_nseg", C.c_int), ("lora_seg_width", C.c_int),
         ("lora_scale", C.c_float),
         ("a_mode", C.c_int), ("img_res", C.c_int), ("patch", C.c_int), ("out_tokens", C.c_int),
-        ("B_planes", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t),
+        ("B_planes", C.c_void_p), ("b_format", C.c_int), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t),
     ]
 
 
@@ -53,7 +53,7 @@ class Tower(C.Structure):
         ("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("seq", C.c_int), ("causal", C.c_int),
         ("lora_r", C.c_int), ("lora_scale", C.c_float), ("lora_dropout", C.c_float),
         ("dropout_seed", C.c_uint64), ("dropout_stream0", C.c_uint32),
-        ("blocks", C.POINTER(Block)),
+        ("blocks", C.POINTER(Block)), ("weight_format", C.c_int),
     ]
 
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "clipfs_last_error": (C.c_char_p, []),
     "clipfs_gemm_nt": (_i, [C.POINTER(GemmArgs), _p]),
     "clipfs_split_bf16": (_i, [_p, _p, _sz, _p]),
+    "clipfs_convert_f16": (_i, [_p, _p, _sz, _p]),
     "clipfs_gemm_splits": (_i, [_i, _i, _i]),
     "clipfs_gemm_workspace_floats": (_sz, [_i, _i, _i]),
     "clipfs_gemm_timing": (_i, [_i]),

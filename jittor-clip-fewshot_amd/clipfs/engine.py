@@ -46,7 +46,7 @@ class _TowerRT:
         self._keep: list = []
         self._bufs: Dict[Tuple[str, int], torch.Tensor] = {}
         self._wt: Dict[int, Dict[str, torch.Tensor]] = {}
-        self._planes: Dict[Tuple[int, str], torch.Tensor] = {}
+        self._planes: Dict[Tuple[int, str, str], torch.Tensor] = {}
         self.precision = "fp32"  # "fp32": exact v_mfma_f32_32x32x2_f32 | "bf16x3": split-bf16, 3 MFMA products
         self.lora_r = 0
         self.lora_scale = 0.0
@@ -65,10 +65,10 @@ class _TowerRT:
         return wt
 
     def _plane(self, i: int, name: str, w: torch.Tensor) -> torch.Tensor:
-        key = (i, name)
+        key = (i, name, self.precision)
         pl = self._planes.get(key)
         if pl is None:
-            pl = ops.split_bf16(w.contiguous())
+            pl = ops.split_bf16(w.contiguous()) if self.precision == "bf16x3" else ops.to_f16(w.contiguous())
             self._planes[key] = pl
         return pl
 
@@ -93,7 +93,7 @@ class _TowerRT:
             if train:
                 wt = self._transposed(i, blk)
                 b.w_qkv_t, b.w_o_t, b.w_fc_t, b.w_pr_t = _ptr(wt["qkv"]), _ptr(wt["o"]), _ptr(wt["fc"]), _ptr(wt["pr"])
-            if self.precision == "bf16x3":
+            if self.precision != "fp32":
                 b.w_qkv_p = _ptr(self._plane(i, "qkv", w_qkv.data))
                 b.w_o_p = _ptr(self._plane(i, "o", w_o.data))
                 b.w_fc_p = _ptr(self._plane(i, "fc", blk.mlp.c_fc.weight.data))
@@ -120,6 +120,7 @@ class _TowerRT:
         t.lora_r, t.lora_scale, t.lora_dropout = r, scale, p
         t.dropout_seed = seed if (train and p > 0) else 0
         t.dropout_stream0 = self.stream0
+        t.weight_format = {"fp32": 0, "bf16x3": 1, "fp16": 2}[self.precision]
         t.blocks = C.cast(blocks, C.POINTER(Block))
         t._blocks_keepalive = blocks  # ctypes array must outlive the call
         self.lora_r, self.lora_scale, self.lora_dropout = r, scale, p
@@ -183,9 +184,10 @@ class Engine:
         """"fp32" (default): every GEMM on the exact fp32 MFMA.  "bf16x3": the tower GEMMs (97 % of the FLOPs) run
         as split-bf16 with three bf16 MFMA products per operand pair, fp32 accumulate (weights are split once;
         logits move by ~2e-4 on 100 x cosine, inside the 1e-3 budget).  LayerNorm, attention, LoRA, the patch /
-        projection / logits GEMMs and all reductions stay fp32."""
-        if mode not in ("fp32", "bf16x3"):
-            raise ValueError("precision must be 'fp32' or 'bf16x3'")
+        projection / logits GEMMs and all reductions stay fp32.  "fp16": the same GEMMs with f16 operands
+        (v_mfma_f32_32x32x16_f16, fp32 accumulate) -- cfg-5's "MFMA fp16 path"; tolerance ~1e-2 on the logits."""
+        if mode not in ("fp32", "bf16x3", "fp16"):
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'fp16'")
         self.vis.precision = mode
         self.txt.precision = mode
 

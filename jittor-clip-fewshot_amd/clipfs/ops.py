@@ -57,6 +57,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         g.lora_seg_width = lora_seg_width or N
         g.lora_scale = lora_scale
     g.B_planes = _p(b_planes)
+    if b_planes is not None:
+        g.b_format = 2 if b_planes.dtype == torch.float16 else 1
     lib = _lib.load()
     ws = None
     nws = lib.clipfs_gemm_workspace_floats(M, N, K) if split_k else 0
@@ -73,6 +75,14 @@ def split_bf16(w: torch.Tensor) -> torch.Tensor:
     planes = torch.empty((2,) + tuple(w.shape), device=w.device, dtype=torch.int16)
     check(_lib.load().clipfs_split_bf16(_p(w), _p(planes), w.numel(), _stream()), "split_bf16")
     return planes
+
+
+def to_f16(w: torch.Tensor) -> torch.Tensor:
+    """f16 plane of a frozen fp32 weight (fp16 MFMA mode)."""
+    _f32(w)
+    out = torch.empty(w.shape, device=w.device, dtype=torch.float16)
+    check(_lib.load().clipfs_convert_f16(_p(w), _p(out), w.numel(), _stream()), "convert_f16")
+    return out
 
 
 def patch_embed(images: torch.Tensor, conv_w: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, tokens: int) -> None:

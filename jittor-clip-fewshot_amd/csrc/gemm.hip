@@ -422,7 +422,8 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   p.splits = 1;
   p.part = nullptr;
   p.n_blocks_n = 0;
-  if (a.B_planes && a.a_mode == 0 && (a.K % BK) == 0 && a.ldb == a.K) return gemm_bf16x3_dispatch(p, s);
+  if (a.B_planes && (a.b_format == 1 || a.b_format == 2) && a.a_mode == 0 && (a.K % BK) == 0 && a.ldb == a.K)
+    return gemm_bf16x3_dispatch(p, s);
   {
     const int want = clipfs_gemm_splits(a.M, a.N, a.K);
     if (want > 1 && a.workspace && a.workspace_floats >= (size_t)want * a.M * a.N) {

@@ -21,6 +21,7 @@
 namespace clipfs {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void glds16b(const void* gsrc, void* lds_wave_base) {
@@ -55,18 +56,36 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 
 struct Bf16Params {
   GemmParams g;
-  const __bf16* b_hi;  // [N, K]
-  const __bf16* b_lo;
+  const void* b_hi;  // [N, K] 16-bit plane (bf16 hi, or the single f16 plane)
+  const void* b_lo;  // bf16 lo plane (unused for f16)
 };
 
-template <int BM, int BN>
+__device__ __forceinline__ f16x8 to_f16x8(const f32x4& x0, const f32x4& x1) {
+  f16x8 h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = (_Float16)x0[j];
+    h[4 + j] = (_Float16)x1[j];
+  }
+  return h;
+}
+
+__global__ __launch_bounds__(256) void convert_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst,
+                                                          size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256)
+    *reinterpret_cast<f16x8*>(dst + 8 * i) = to_f16x8(*reinterpret_cast<const f32x4*>(src + 8 * i),
+                                                      *reinterpret_cast<const f32x4*>(src + 8 * i + 4));
+}
+
+// NPL = number of 16-bit planes per operand: 2 = bf16 hi/lo (3 MFMA products), 1 = f16 (1 product; cfg-5's fp16 path)
+template <int BM, int BN, int NPL>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const Bf16Params bp) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave (2 x 2 waves)
   constexpr int A_UNITS = BM * 4 / 256;              // (row, 8-k chunk) units staged per thread
-  constexpr int B_INSTR = 2 * BN / 16 / 4;           // global_load_lds instructions per wave per K-step (2 planes)
+  constexpr int B_INSTR = NPL * BN / 16 / 4;         // global_load_lds instructions per wave per K-step
   constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;  // bytes
-  constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_B;
+  constexpr int STAGE = NPL * PLANE_A + NPL * PLANE_B;
 
   const GemmParams& p = bp.g;
   const clipfs_gemm_args& g = p.a;
@@ -102,9 +121,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const Bf16Params bp) {
     for (int i = 0; i < B_INSTR; ++i) {
       const int q = uw + 4 * i, plane = q / (BN / 16), r0 = 16 * (q % (BN / 16));
       const int row = r0 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
-      const __bf16* base = plane ? bp.b_lo : bp.b_hi;
-      b_src[i] = reinterpret_cast<const char*>(base + (size_t)min(n0 + row, N - 1) * g.ldb + 8 * c);
-      b_off[i] = 2 * PLANE_A + plane * PLANE_B + r0 * 64;
+      const char* base = reinterpret_cast<const char*>(plane ? bp.b_lo : bp.b_hi);
+      b_src[i] = base + ((size_t)min(n0 + row, N - 1) * g.ldb + 8 * c) * 2;
+      b_off[i] = NPL * PLANE_A + plane * PLANE_B + r0 * 64;
     }
   }
   // ---- fragment addresses ---------------------------------------------------------------------------------
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const Bf16Params bp) {
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int row = wn * (BN / 2) + t * 32 + fr;
-    b_frag[t] = 2 * PLANE_A + row * 64;
+    b_frag[t] = NPL * PLANE_A + row * 64;
     b_swz[t] = (row >> 2) & 3;
   }
 
@@ -148,36 +167,55 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const Bf16Params bp) {
     char* s = smem_raw + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < A_UNITS; ++i) {
-      bf16x8 hi, lo;
-      split8(areg[i][0], areg[i][1], hi, lo);
-      *reinterpret_cast<bf16x8*>(s + a_off[i]) = hi;
-      *reinterpret_cast<bf16x8*>(s + PLANE_A + a_off[i]) = lo;
+      if constexpr (NPL == 2) {
+        bf16x8 hi, lo;
+        split8(areg[i][0], areg[i][1], hi, lo);
+        *reinterpret_cast<bf16x8*>(s + a_off[i]) = hi;
+        *reinterpret_cast<bf16x8*>(s + PLANE_A + a_off[i]) = lo;
+      } else {
+        *reinterpret_cast<f16x8*>(s + a_off[i]) = to_f16x8(areg[i][0], areg[i][1]);
+      }
     }
   };
   auto compute = [&](const char* s) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      if constexpr (NPL == 2) {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        const int o = a_frag[t] + (((2 * kb + fh) ^ a_swz[t]) << 4);
-        ah[t] = *reinterpret_cast<const bf16x8*>(s + o);
-        al[t] = *reinterpret_cast<const bf16x8*>(s + PLANE_A + o);
-      }
-#pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        const int o = b_frag[t] + (((2 * kb + fh) ^ b_swz[t]) << 4);
-        bh[t] = *reinterpret_cast<const bf16x8*>(s + o);
-        bl[t] = *reinterpret_cast<const bf16x8*>(s + PLANE_B + o);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < TM; ++t) {
+          const int o = a_frag[t] + (((2 * kb + fh) ^ a_swz[t]) << 4);
+          ah[t] = *reinterpret_cast<const bf16x8*>(s + o);
+          al[t] = *reinterpret_cast<const bf16x8*>(s + PLANE_A + o);
         }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          const int o = b_frag[t] + (((2 * kb + fh) ^ b_swz[t]) << 4);
+          bh[t] = *reinterpret_cast<const bf16x8*>(s + o);
+          bl[t] = *reinterpret_cast<const bf16x8*>(s + PLANE_B + o);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      } else {
+        f16x8 av[TM], bv[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+          av[t] = *reinterpret_cast<const f16x8*>(s + a_frag[t] + (((2 * kb + fh) ^ a_swz[t]) << 4));
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          bv[t] = *reinterpret_cast<const f16x8*>(s + b_frag[t] + (((2 * kb + fh) ^ b_swz[t]) << 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
     }
   };
 
@@ -211,19 +249,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const Bf16Params bp) {
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NPL>
 static int launch_bf16(Bf16Params& bp, hipStream_t stream) {
   const clipfs_gemm_args& a = bp.g.a;
   bp.g.n_blocks_n = (a.N + BN - 1) / BN;
   const int mb = (a.M + BM - 1) / BM;
-  const size_t lds = 2 * (size_t)(2 * BM * 64 + 2 * BN * 64);
+  const size_t lds = 2 * (size_t)(NPL * BM * 64 + NPL * BN * 64);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<BM, BN, NPL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN>), dim3(mb * bp.g.n_blocks_n), dim3(256), lds, stream, bp);
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<BM, BN, NPL>), dim3(mb * bp.g.n_blocks_n), dim3(256), lds, stream, bp);
   return launch_status();
 }
 
@@ -233,17 +271,28 @@ int gemm_bf16x3_dispatch(const GemmParams& base, hipStream_t stream) {
   bp.g = base;
   bp.g.splits = 1;
   const clipfs_gemm_args& a = base.a;
-  bp.b_hi = reinterpret_cast<const __bf16*>(a.B_planes);
-  bp.b_lo = bp.b_hi + (size_t)a.N * a.ldb;
+  bp.b_hi = a.B_planes;
+  bp.b_lo = reinterpret_cast<const char*>(a.B_planes) + (size_t)a.N * a.ldb * 2;
   static const int tile_cfg = getenv("CLIPFS_BF16_TILE") ? atoi(getenv("CLIPFS_BF16_TILE")) : 0;
   const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  if (tile_cfg == 1 || (tile_cfg == 0 && t128 >= 1024)) return launch_bf16<128, 128>(bp, stream);
-  return launch_bf16<64, 128>(bp, stream);
+  const bool big = tile_cfg == 1 || (tile_cfg == 0 && t128 >= 1024);
+  if (a.b_format == 2) return big ? launch_bf16<128, 128, 1>(bp, stream) : launch_bf16<64, 128, 1>(bp, stream);
+  return big ? launch_bf16<128, 128, 2>(bp, stream) : launch_bf16<64, 128, 2>(bp, stream);
 }
 
 }  // namespace clipfs
 
 using namespace clipfs;
+
+extern "C" int clipfs_convert_f16(const float* src, void* dst, size_t n, void* stream) {
+  CLIPFS_REQUIRE(src && dst && n > 0 && (n & 7) == 0 && aligned16(src) && aligned16(dst),
+                 "convert_f16: n must be a multiple of 8, pointers 16-byte aligned");
+  const size_t n8 = n / 8;
+  const unsigned blocks = (unsigned)((n8 + 255) / 256 > 8192 ? 8192 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(convert_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                     reinterpret_cast<_Float16*>(dst), n8);
+  return launch_status();
+}
 
 extern "C" int clipfs_split_bf16(const float* src, void* planes, size_t n, void* stream) {
   CLIPFS_REQUIRE(src && planes && n > 0 && (n & 7) == 0 && aligned16(src) && aligned16(planes),

@@ -72,12 +72,14 @@ static int check_tower(const clipfs_tower* t, int batch) {
 
 static thread_local float* g_ws = nullptr;  // split-K scratch of the tower call in progress (its scratch buffer)
 static thread_local size_t g_ws_floats = 0;
+static thread_local int g_b_format = 0;  // format of the blocks' 16-bit weight copies for the call in progress
 
 static int gemm(const float* A, const float* B, const void* Bp, float* C, int M, int N, int K, const float* bias,
                 const float* res, int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r,
                 int nseg, int segw, float lscale, hipStream_t st) {
   clipfs_gemm_args a = {};
   a.B_planes = Bp;
+  a.b_format = g_b_format;
   a.workspace = g_ws;
   a.workspace_floats = g_ws_floats;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
@@ -112,6 +114,7 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
   const bool train = saved != nullptr;
   g_ws = scratch + SC.gemm_ws;
   g_ws_floats = SC.gemm_ws_floats;
+  g_b_format = t->weight_format;
   const uint64_t seed = train ? t->dropout_seed : 0;  // dropout only when training (is_training(), :298)
   if (train) {
     hipError_t e = hipMemcpyAsync(saved + SL.x_in, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -164,6 +167,7 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
   const ScratchLayout SC = scratch_layout(t, (size_t)M);
   g_ws = scratch + SC.gemm_ws;
   g_ws_floats = SC.gemm_ws_floats;
+  g_b_format = t->weight_format;
   const uint64_t seed = t->dropout_seed;
   for (int l = t->layers - 1; l >= 0; --l) {
     const clipfs_block& b = t->blocks[l];

@@ -431,3 +431,35 @@ def test_vit_l14_shapes(dev, monkeypatch):
             for nm, prm in (("w_lora_A", m.w_lora_A), ("w_lora_B", m.w_lora_B)):
                 worst = max(worst, _err(pairs[id(prm)], blks[i][names[pr]][nm].grad))
     assert worst < 1e-4 * max(gmax, 1e-3), (worst, gmax)
+
+
+def test_fp16_precision_mode_l14(dev, monkeypatch):
+    """cfg-5's fp16 MFMA path on ViT-L/14 shapes (depth 2 + 2, LoRA r = 16): tower GEMMs with f16 operands.  The
+    tolerance is fp16's, stated here: logits (100 x cosine) within 5e-2 of the fp64 oracle ("the
+    fp16 MFMA path cannot meet 1e-3 vs an fp32 oracle; state its tolerance separately"), top-1 unchanged."""
+    import dataclasses
+    import lora_train_vlp as L
+    from clipfs import synth
+    from oracle import clip_oracle as O
+    cfg = dataclasses.replace(synth.VIT_L14, vision_layers=2, transformer_layers=2, vocab_size=2048)
+    sd, model = _build(cfg, dev, seed=17)
+    args = _args("ViT-L/14", r=16)
+    lw = synth.synth_lora(cfg, 16, seed=5)
+    _apply(model, cfg, args, lw, monkeypatch)
+    B, Cn = 4, 6
+    img = synth.synth_images(B, 224, seed=3)
+    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=4, max_len=20)
+    tgt = synth.synth_labels(B, Cn, seed=2)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    tl, vl = _oracle_lora(lw, cfg)
+    with torch.no_grad():
+        _, wl = O.train_step_loss(sd64, img.double(), cap, tgt, tl, vl, 0.25, text_chunk=Cn)
+    model.eval()
+    model.engine.precision = "fp16"
+    tr = L.LoRATrainer(model)
+    tr.flat.zero_grad()
+    _, _, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+    e = _err(logits, wl)
+    assert 1e-5 < e < 5e-2, e
+    assert torch.equal(logits.argmax(1).cpu(), wl.argmax(1))
+    assert torch.isfinite(tr.flat.grads).all() and tr.flat.grads.abs().max() > 0

@@ -373,3 +373,19 @@ def test_gemm_bf16x3(dev, M, N, K):
     assert err < 6e-5, err
     exact = ops.gemm_nt(D(a), D(w), bias=D(bias), residual=D(res))
     assert (exact.double().cpu() - want).abs().max().item() < err * 2 + 1e-5  # sanity: fp32 path at least comparable
+
+
+def test_gemm_f16_mode(dev):
+    """fp16-operand MFMA kernel (cfg-5's "MFMA fp16 path"): operands rounded to f16, fp32 accumulate -- the result
+    equals the fp64 product of the ROUNDED operands to fp32 accuracy; vs the unrounded product the error is that of
+    fp16 rounding (2^-11 relative per operand)."""
+    from clipfs import ops
+    M, N, K = 300, 768, 1024
+    a, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    D = lambda x: x.float().to(dev)
+    plane = ops.to_f16(D(w))
+    assert plane.dtype == torch.float16 and torch.equal(plane.cpu(), w.float().half())
+    out = ops.gemm_nt(D(a), D(w), b_planes=plane)
+    rounded = a.float().half().double() @ w.float().half().double().t()
+    _close(out, rounded, 2e-5, "f16 gemm vs rounded operands")
+    assert (out.double().cpu() - a @ w.t()).abs().max().item() < 5e-3
