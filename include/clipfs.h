@@ -15,8 +15,9 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
  *   - return value: 0 = ok, CLIPFS_EINVAL = bad argument (nothing launched),
  *     otherwise 1000 + hipError_t of the failed launch;
- *   - no entry point allocates, frees, synchronises or keeps global state: all
- *     buffers (workspaces included) are owned by the caller (PyTorch-ROCm tensors).
+ *   - no entry point allocates or frees device memory or synchronises the stream: all buffers (workspaces
+ *     included) are owned by the caller (PyTorch-ROCm tensors).  The only state kept is per host thread:
+ *     the last error string and, while enabled, the GEMM timing events (clipfs_gemm_timing).
  */
 #ifndef CLIPFS_H
 #define CLIPFS_H

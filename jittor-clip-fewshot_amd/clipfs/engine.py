@@ -43,7 +43,6 @@ class _TowerRT:
         self.layers = transformer.layers
         self.causal = bool(transformer.causal)
         self.stream0 = stream0
-        self._keep: list = []
         self._bufs: Dict[Tuple[str, int], torch.Tensor] = {}
         self._wt: Dict[int, Dict[str, torch.Tensor]] = {}
         self._planes: Dict[Tuple[int, str, str], torch.Tensor] = {}
@@ -74,7 +73,6 @@ class _TowerRT:
 
     def descriptor(self, train: bool, seed: int, seq: Optional[int] = None) -> Tower:
         blocks = (Block * self.layers)()
-        keep = []
         r, scale, p = 0, 0.0, 0.0
         for i, blk in enumerate(self.mod.resblocks):
             a = blk.attn

@@ -473,6 +473,178 @@ __global__ __launch_bounds__(256) void attention_generic_bwd_kv_kernel(const flo
   dqkv[((size_t)b * L + j) * ld + d + h * HD + lane] = ak;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Medium sequences (96 < L <= 300; ViT-L/14: 257): one workgroup of 8 waves per (batch, head) with the head's K and V
+// (or Q and dO) resident in LDS -- 2 x L x 68 floats = 140 KB at L = 257 -- instead of being re-streamed from L2 per
+// query row.  A wave owns one query (key) row at a time: its row is wave-uniform (scalar loads), the LDS rows are
+// read by the lane that owns that key (16 conflict-free ds_read_b128 at row stride 68) and column-wise
+// (ds_read_b32, lane = feature) for the accumulations; online softmax over key blocks of 64.
+// ---------------------------------------------------------------------------------------------------------
+
+// acc[lane] += sum_{t < n} vec[t] * rows[(j0 + t) * KSTRIDE + lane]     (rows: LDS image, vec: the wave's LDS slot)
+__device__ __forceinline__ float axpy_block_lds(const float* __restrict__ vec, const float* __restrict__ rows, int lane,
+                                                int n, float acc) {
+  float a0 = acc, a1 = 0.f;
+  int t = 0;
+  for (; t + 4 <= n; t += 4) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(vec + t);
+    a0 = fmaf(p[0], rows[(t + 0) * KSTRIDE + lane], a0);
+    a1 = fmaf(p[1], rows[(t + 1) * KSTRIDE + lane], a1);
+    a0 = fmaf(p[2], rows[(t + 2) * KSTRIDE + lane], a0);
+    a1 = fmaf(p[3], rows[(t + 3) * KSTRIDE + lane], a1);
+  }
+  for (; t < n; ++t) a0 = fmaf(vec[t], rows[t * KSTRIDE + lane], a0);
+  return a0 + a1;
+}
+
+__device__ __forceinline__ void stage_rows_n(const float* __restrict__ base, size_t ld, float* __restrict__ dst, int L) {
+  for (int idx = threadIdx.x; idx < L * (HD / 4); idx += (int)blockDim.x) {
+    const int r = idx >> 4, c = idx & 15;
+    *reinterpret_cast<f32x4*>(dst + r * KSTRIDE + 4 * c) = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld + 4 * c);
+  }
+}
+
+__global__ __launch_bounds__(512) void attention_lds_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                float* __restrict__ lse, int L, int H, int causal) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sK = smem;
+  float* sV = sK + L * KSTRIDE;
+  float* sP = sV + L * KSTRIDE;  // [8][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = H * HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
+  stage_rows_n(q0 + d, ld, sK, L);
+  stage_rows_n(q0 + 2 * d, ld, sV, L);
+  __syncthreads();
+  float* myP = sP + wave * 64;
+  for (int i = wave; i < L; i += 8) {
+    f32x4 q[HD / 4];
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) q[c] = *reinterpret_cast<const f32x4*>(q0 + (size_t)i * ld + 4 * c);  // uniform
+    float m = -INFINITY, l = 0.f, o = 0.f;
+    const int jend = causal ? i + 1 : L;
+    for (int j0 = 0; j0 < jend; j0 += 64) {
+      const int j = j0 + lane;
+      float sc = -INFINITY;
+      if (j < jend) sc = dot64_row(q, sK + j * KSTRIDE) * 0.125f;
+      const float mn = fmaxf(m, wave_max(sc));
+      const float pj = __expf(sc - mn);
+      const float f = __expf(m - mn);
+      l = l * f + wave_sum(pj);
+      myP[lane] = pj;
+      __builtin_amdgcn_wave_barrier();
+      o = axpy_block_lds(myP, sV + j0 * KSTRIDE, lane, min(64, jend - j0), o * f);
+      __builtin_amdgcn_wave_barrier();
+      m = mn;
+    }
+    out[((size_t)b * L + i) * d + h * HD + lane] = o / l;
+    if (lse && lane == 0) lse[((size_t)b * H + h) * L + i] = m + __logf(l);
+  }
+}
+
+__global__ __launch_bounds__(512) void attention_lds_bwd_q_kernel(const float* __restrict__ qkv,
+                                                                  const float* __restrict__ dout,
+                                                                  const float* __restrict__ out,
+                                                                  const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                                  float* __restrict__ Dbuf, int L, int H, int causal) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sK = smem;
+  float* sV = sK + L * KSTRIDE;
+  float* sP = sV + L * KSTRIDE;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = H * HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
+  stage_rows_n(q0 + d, ld, sK, L);
+  stage_rows_n(q0 + 2 * d, ld, sV, L);
+  __syncthreads();
+  float* myP = sP + wave * 64;
+  for (int i = wave; i < L; i += 8) {
+    const float* do_i = dout + ((size_t)b * L + i) * d + h * HD;
+    f32x4 q[HD / 4], g[HD / 4];
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      q[c] = *reinterpret_cast<const f32x4*>(q0 + (size_t)i * ld + 4 * c);
+      g[c] = *reinterpret_cast<const f32x4*>(do_i + 4 * c);
+    }
+    const float Di = wave_sum(do_i[lane] * out[((size_t)b * L + i) * d + h * HD + lane]);
+    const float li = lse[((size_t)b * H + h) * L + i];
+    if (lane == 0) Dbuf[((size_t)b * H + h) * L + i] = Di;
+    float acc = 0.f;
+    const int jend = causal ? i + 1 : L;
+    for (int j0 = 0; j0 < jend; j0 += 64) {
+      const int j = j0 + lane;
+      float ds = 0.f;
+      if (j < jend) {
+        const float pj = __expf(dot64_row(q, sK + j * KSTRIDE) * 0.125f - li);
+        ds = pj * (dot64_row(g, sV + j * KSTRIDE) - Di) * 0.125f;
+      }
+      myP[lane] = ds;
+      __builtin_amdgcn_wave_barrier();
+      acc = axpy_block_lds(myP, sK + j0 * KSTRIDE, lane, min(64, jend - j0), acc);
+      __builtin_amdgcn_wave_barrier();
+    }
+    dqkv[((size_t)b * L + i) * ld + h * HD + lane] = acc;
+  }
+}
+
+__global__ __launch_bounds__(512) void attention_lds_bwd_kv_kernel(const float* __restrict__ qkv,
+                                                                   const float* __restrict__ dout,
+                                                                   const float* __restrict__ lse,
+                                                                   const float* __restrict__ Dbuf,
+                                                                   float* __restrict__ dqkv, int L, int H, int causal) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sQ = smem;
+  float* sG = sQ + L * KSTRIDE;  // dO rows
+  float* sP = sG + L * KSTRIDE;  // [8][64] p, then [8][64] dS
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = H * HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * HD;
+  stage_rows_n(q0, ld, sQ, L);
+  stage_rows_n(dout + (size_t)b * L * d + (size_t)h * HD, (size_t)d, sG, L);
+  __syncthreads();
+  float* myP = sP + wave * 64;
+  float* myS = sP + 8 * 64 + wave * 64;
+  const float* lse0 = lse + ((size_t)b * H + h) * L;
+  const float* D0 = Dbuf + ((size_t)b * H + h) * L;
+  for (int j = wave; j < L; j += 8) {
+    f32x4 k[HD / 4], v[HD / 4];
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      k[c] = *reinterpret_cast<const f32x4*>(q0 + d + (size_t)j * ld + 4 * c);
+      v[c] = *reinterpret_cast<const f32x4*>(q0 + 2 * d + (size_t)j * ld + 4 * c);
+    }
+    float av = 0.f, ak = 0.f;
+    const int ibeg = causal ? j : 0;
+    for (int i0 = ibeg & ~63; i0 < L; i0 += 64) {
+      const int i = i0 + lane;
+      float pj = 0.f, ds = 0.f;
+      if (i < L && i >= ibeg) {
+        pj = __expf(dot64_row(k, sQ + i * KSTRIDE) * 0.125f - lse0[i]);
+        ds = pj * (dot64_row(v, sG + i * KSTRIDE) - D0[i]) * 0.125f;
+      }
+      myP[lane] = pj;
+      myS[lane] = ds;
+      __builtin_amdgcn_wave_barrier();
+      const int n = min(64, L - i0);
+      av = axpy_block_lds(myP, sG + i0 * KSTRIDE, lane, n, av);
+      ak = axpy_block_lds(myS, sQ + i0 * KSTRIDE, lane, n, ak);
+      __builtin_amdgcn_wave_barrier();
+    }
+    dqkv[((size_t)b * L + j) * ld + 2 * d + h * HD + lane] = av;
+    dqkv[((size_t)b * L + j) * ld + d + h * HD + lane] = ak;
+  }
+}
+
 static int check_attn(const char* what, int batch, int seq, int heads, int max_seq) {
   CLIPFS_REQUIRE(batch > 0 && heads > 0 && seq > 0 && seq <= max_seq, "%s: batch %d seq %d heads %d unsupported (seq <= %d)",
                  what, batch, seq, heads, max_seq);
@@ -493,12 +665,24 @@ using namespace clipfs;
 
 constexpr int ATTN_FAST_MAX = 96;   // register/LDS-resident kernels up to here (forward-only inference: 128)
 constexpr int ATTN_MAX_SEQ = 4096;
+constexpr int ATTN_LDS_MAX = 288;    // (2 * L * 68 + 16 * 64) floats <= 160 KiB: K and V (or Q and dO) of a head stay in LDS
 
 extern "C" int clipfs_attention_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal,
                                     void* stream) {
   CLIPFS_CHECK(check_attn("attention_fwd", batch, seq, heads, ATTN_MAX_SEQ));
   CLIPFS_REQUIRE(qkv && out && aligned16(qkv), "attention_fwd: null or misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
+  if ((seq > 128 || (seq > ATTN_FAST_MAX && lse)) && seq <= ATTN_LDS_MAX) {
+    const size_t lds = ((size_t)2 * seq * KSTRIDE + 8 * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_lds_fwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(attention_lds_fwd_kernel, dim3(batch * heads), dim3(512), lds, st, qkv, out, lse, seq, heads, causal);
+    return launch_status();
+  }
   if (seq > 128 || (seq > ATTN_FAST_MAX && lse)) {
     hipLaunchKernelGGL(attention_generic_fwd_kernel, dim3(batch * heads, (seq + 3) / 4), dim3(256), 0, st, qkv, out, lse,
                        seq, heads, causal);
@@ -527,6 +711,23 @@ extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, const f
   if (seq > ATTN_FAST_MAX) {
     CLIPFS_REQUIRE(out && lse && work, "attention_bwd: seq %d > %d needs the forward's out and lse and a work buffer", seq,
                    ATTN_FAST_MAX);
+    if (seq <= ATTN_LDS_MAX) {
+      const size_t lds = ((size_t)2 * seq * KSTRIDE + 16 * 64) * sizeof(float);
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_lds_bwd_q_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_lds_bwd_kv_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+      }
+      hipLaunchKernelGGL(attention_lds_bwd_q_kernel, dim3(batch * heads), dim3(512), lds, st, qkv, dout, out, lse, dqkv,
+                         work, seq, heads, causal);
+      CLIPFS_CHECK(launch_status());
+      hipLaunchKernelGGL(attention_lds_bwd_kv_kernel, dim3(batch * heads), dim3(512), lds, st, qkv, dout, lse, work, dqkv,
+                         seq, heads, causal);
+      return launch_status();
+    }
     const dim3 grid(batch * heads, (seq + 3) / 4);
     hipLaunchKernelGGL(attention_generic_bwd_q_kernel, grid, dim3(256), 0, st, qkv, dout, out, lse, dqkv, work, seq, heads,
                        causal);

@@ -17,13 +17,12 @@ from __future__ import annotations
 import math
 import os
 import pickle
-from typing import Dict, List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
 from torch import nn
 
-from clipfs import engine as E
 from clipfs import ops, safe_pkl
 from jclip import clip
 

@@ -129,7 +129,7 @@ def test_layernorm_strided_rows(dev):
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,L,H,causal", [(3, 50, 2, False), (2, 54, 12, False), (3, 77, 8, True), (2, 16, 1, True),
                                           (1, 5, 2, False), (2, 96, 2, True), (2, 257, 2, False), (1, 130, 1, True),
-                                          (1, 100, 2, False)])
+                                          (1, 100, 2, False), (1, 288, 1, True), (1, 330, 2, False), (1, 289, 1, True)])
 def test_attention(dev, B, L, H, causal):
     from clipfs import ops
     from oracle import clip_oracle as O
