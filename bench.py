@@ -164,11 +164,19 @@ def main():
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP engine has no CPU fallback)")
+    # CLIPFS_BENCH_REHEARSE=1: run the N-rank code path on a box with fewer GPUs than ranks (ranks share cards, gloo
+    # instead of RCCL, which refuses two ranks on one device).  A correctness rehearsal only -- never a measurement.
+    rehearse = os.environ.get("CLIPFS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from clipfs import _lib, dist as D, synth
     model, tr, cfg = build_trainer(dev, args, world)

@@ -30,16 +30,26 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
             act: int = 0, aux_out=None, aux_in=None, alpha: float = 1.0, lora_t=None, lora_b=None,
-            lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True, b_planes=None) -> torch.Tensor:
-    """out = epi(alpha * a @ b.T); a [M,K], b [N,K]."""
-    _f32(a), _f32(b)
-    M, K = a.shape
+            lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True, b_planes=None,
+            a16: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(alpha * a @ b.T); a [M,K], b [N,K].  ``a16`` (f16 [M,K]) with f16 ``b_planes`` selects the
+    f16 x f16 kernel (``a`` may then be None); ``out16`` (f16 [M,N]) receives an f16 copy of the result."""
+    if a is not None:
+        _f32(a)
+    _f32(b)
+    M, K = (a16 if a is None else a).shape
     N = b.shape[0]
     assert b.shape[1] == K
     if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+        out = torch.empty(M, N, device=b.device, dtype=torch.float32)
     g = GemmArgs()
     g.A, g.B, g.C = _p(a), _p(b), _p(out)
+    if a16 is not None:
+        assert a16.dtype == torch.float16 and a16.is_contiguous() and tuple(a16.shape) == (M, K)
+        g.A_f16 = _p(a16)
+    if out16 is not None:
+        assert out16.dtype == torch.float16 and out16.is_contiguous() and tuple(out16.shape) == (M, N)
+        g.C_f16 = _p(out16)
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb, g.ldc = K, K, N
     g.alpha = alpha
@@ -63,7 +73,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     ws = None
     nws = lib.clipfs_gemm_workspace_floats(M, N, K) if split_k else 0
     if nws:
-        ws = torch.empty(nws, device=a.device, dtype=torch.float32)
+        ws = torch.empty(nws, device=b.device, dtype=torch.float32)
         g.workspace, g.workspace_floats = _p(ws), nws
     check(lib.clipfs_gemm_nt(C.byref(g), _stream()), "gemm_nt")
     return out

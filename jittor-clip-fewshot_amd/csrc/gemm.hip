@@ -369,6 +369,7 @@ extern "C" int clipfs_gemm_timing_collect(double* total_ms, double* total_flops,
 
 namespace clipfs {
 int gemm_bf16x3_dispatch(const GemmParams& base, hipStream_t stream);  // gemm_bf16.hip
+int gemm_f16_dispatch(const clipfs_gemm_args& a, hipStream_t stream);  // gemm_f16.hip
 }
 
 static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream);
@@ -390,8 +391,21 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
 static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   CLIPFS_REQUIRE(args != nullptr, "gemm: null args");
   const clipfs_gemm_args& a = *args;
-  CLIPFS_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
   CLIPFS_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad dims %d %d %d", a.M, a.N, a.K);
+  if (a.A_f16) {  // f16 x f16 kernel
+    CLIPFS_REQUIRE(a.B_planes && a.b_format == 2, "gemm: A_f16 needs the f16 copy of B (b_format 2)");
+    CLIPFS_REQUIRE(a.C || a.C_f16, "gemm: no output");
+    CLIPFS_REQUIRE(a.a_mode == 0 && (a.K % BK) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0 && a.lda >= a.K && a.ldb >= a.K &&
+                       a.ldc >= a.N && aligned16(a.A_f16) && aligned16(a.B_planes),
+                   "gemm f16: K %% 32, lda/ldb %% 8, 16-byte aligned operands required");
+    CLIPFS_REQUIRE(a.act >= 0 && a.act <= 2 && (a.act != 2 || a.aux_in) && (!a.residual || a.ldres >= a.N), "gemm f16: bad epilogue args");
+    if (a.lora_t)
+      CLIPFS_REQUIRE(a.lora_b && a.lora_r > 0 && a.lora_r <= 16 && a.lora_nseg > 0 && a.lora_seg_width % 128 == 0 &&
+                         a.lora_seg_width * a.lora_nseg >= a.N, "gemm f16: lora rank <= 16 and segment width %% 128 required");
+    return gemm_f16_dispatch(a, (hipStream_t)stream);
+  }
+  CLIPFS_REQUIRE(!a.C_f16, "gemm: C_f16 is an output of the f16 x f16 kernel only");
+  CLIPFS_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
   CLIPFS_REQUIRE((a.K & 3) == 0 && (a.ldb & 3) == 0 && aligned16(a.B), "gemm: K and ldb must be multiples of 4, B 16-byte aligned");
   CLIPFS_REQUIRE(a.ldb >= a.K && a.ldc >= a.N, "gemm: leading dimension too small");
   CLIPFS_REQUIRE(a.act >= 0 && a.act <= 2, "gemm: bad act %d", a.act);

@@ -1,0 +1,293 @@
+// f16 x f16 -> fp32-accumulate NT GEMM for the fp16 storage mode (cfg-5: ViT-L/14):  C = epi( A16 * B16^T ).
+//
+// Both operands already live in HBM as f16 (the producing kernels write an f16 copy of every tensor that feeds a
+// GEMM; weights are converted once), so the whole K-loop is: global_load_lds_dwordx4 -> LDS -> ds_read_b128 ->
+// v_mfma_f32_32x32x16_f16.  No register staging, no conversion.
+//   * block tile BM x BN x 32, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2) in 32x32 MFMA tiles; 256x128 is the
+//     main shape (128 fp32 accumulators per lane, two workgroups per CU);
+//   * LDS image per operand: [rows][32 k] f16 = 4 chunks of 16 B per row, chunk XOR (row >> 2) & 3 -- the same
+//     conflict-free layout as gemm_bf16.hip; three stages filled two K-steps ahead, one barrier per K-step;
+//   * the rank-r LoRA up-projection (r <= 16) is ONE extra MFMA K-step per tile: A-fragment = the rows of t,
+//     B-fragment = lora_scale * lora_b (zero padded to k = 16), both converted in registers;
+//   * epilogue as gemm_common.h documents it (bias, QuickGELU / x dQuickGELU, residual), writing fp32 C and/or an
+//     f16 copy C16 for the next GEMM.
+// Rows that do not fill a whole BM block are better served by a second launch with a smaller tile (the caller --
+// gemm_f16_dispatch -- cuts M so that the big launch is an exact number of rounds over the CUs).
+#include "gemm_common.h"
+
+#include <stdlib.h>
+
+namespace clipfs {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct F16Params {
+  clipfs_gemm_args a;
+  const _Float16* A16;
+  const _Float16* B16;
+  _Float16* C16;
+  int m_begin;      // first row of this launch (rows [m_begin, m_end) of the problem)
+  int m_end;
+  int n_blocks_n;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_INSTR = BM / 16 / 4, B_INSTR = BN / 16 / 4;  // global_load_lds per wave per K-step
+  constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;          // bytes
+  constexpr int STAGE = PLANE_A + PLANE_B;
+
+  const clipfs_gemm_args& g = p.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int Mend = p.m_end, N = g.N, K = g.K;
+
+  const int tile = xcd_contiguous_unit();
+  constexpr int GM = 8;
+  const int nbn = p.n_blocks_n;
+  const int grp = tile / (GM * nbn);
+  const int rem = tile - grp * (GM * nbn);
+  const int mb_total = (Mend - p.m_begin + BM - 1) / BM;
+  const int gmm = min(GM, mb_total - grp * GM);
+  const int m0 = p.m_begin + (grp * GM + rem % gmm) * BM;
+  const int n0 = (rem / gmm) * BN;
+
+  // ---- staging: instruction q of an operand covers 16 rows x 64 B ---------------------------------------
+  const char* a_src[A_INSTR];
+  const char* b_src[B_INSTR];
+  int a_off[A_INSTR], b_off[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int r0 = 16 * (wave + 4 * i), row = r0 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+    a_src[i] = reinterpret_cast<const char*>(p.A16 + (size_t)min(m0 + row, Mend - 1) * g.lda + 8 * c);
+    a_off[i] = r0 * 64;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int r0 = 16 * (wave + 4 * i), row = r0 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+    b_src[i] = reinterpret_cast<const char*>(p.B16 + (size_t)min(n0 + row, N - 1) * g.ldb + 8 * c);
+    b_off[i] = PLANE_A + r0 * 64;
+  }
+  const int fr = lane & 31, fh = lane >> 5;
+  int a_frag[TM], b_frag[TN], a_swz[TM], b_swz[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * (BM / 2) + t * 32 + fr;
+    a_frag[t] = row * 64;
+    a_swz[t] = (row >> 2) & 3;
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * (BN / 2) + t * 32 + fr;
+    b_frag[t] = PLANE_A + row * 64;
+    b_swz[t] = (row >> 2) & 3;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto stage_in = [&](int kt, int stage) __attribute__((always_inline)) {
+    char* s = smem_raw + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) glds16(a_src[i] + (size_t)kt * (BK * 2), s + a_off[i]);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) glds16(b_src[i] + (size_t)kt * (BK * 2), s + b_off[i]);
+  };
+  // All twelve fragment reads of a K-step are issued before its first MFMA (48 VGPRs): one exposed LDS latency per
+  // K-step instead of one per group of four MFMAs; the second half's reads complete under the first half's MFMAs.
+  auto compute = [&](const char* s) __attribute__((always_inline)) {
+    f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+        av[kb][t] = *reinterpret_cast<const f16x8*>(s + a_frag[t] + (((2 * kb + fh) ^ a_swz[t]) << 4));
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        bv[kb][t] = *reinterpret_cast<const f16x8*>(s + b_frag[t] + (((2 * kb + fh) ^ b_swz[t]) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kb][i], bv[kb][j], acc[i][j], 0, 0, 0);
+  };
+
+  // Three LDS stages, loads issued two K-steps ahead (a K-step is ~1k cycles of MFMA per SIMD, HBM/L2 latency is
+  // of that order): at step kt wait until this wave's loads of stage kt have landed (the newer stage may still be
+  // in flight), barrier (everyone's stage kt is in LDS and everyone is done reading stage kt-1), refill the stage
+  // kt-1 occupied with step kt+2, compute.
+  constexpr int PER_STAGE = A_INSTR + B_INSTR;  // vmcnt events per wave per stage
+  const int nk = K / BK;
+  stage_in(0, 0);
+  if (nk > 1) stage_in(1, 1);
+  int cur = 0, nxt = 2;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) stage_in(kt + 2, nxt);
+    compute(smem_raw + cur * STAGE);
+    cur = cur == 2 ? 0 : cur + 1;
+    nxt = nxt == 2 ? 0 : nxt + 1;
+  }
+
+  // ---- LoRA up-projection: one more K-step of 16 (rank zero-padded), operands converted in registers ----------
+  if (g.lora_t) {
+    const int r = g.lora_r;
+    const int seg = n0 / g.lora_seg_width;  // the host guarantees lora_seg_width % BN == 0
+    f16x8 av[TM], bv[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int m = min(m0 + wm * (BM / 2) + t * 32 + fr, Mend - 1);
+      const float* tp = g.lora_t + (size_t)m * (g.lora_nseg * r) + seg * r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * fh + j;
+        av[t][j] = (_Float16)(tp[min(k, r - 1)] * (k < r ? 1.f : 0.f));
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int n = min(n0 + wn * (BN / 2) + t * 32 + fr, N - 1);
+      const float* lb = g.lora_b + (size_t)n * r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * fh + j;
+        bv[t][j] = (_Float16)(lb[min(k, r - 1)] * (k < r ? g.lora_scale : 0.f));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane owns column n of each 32x32 tile and 16 of its rows (4 groups of 4 consecutive) ---------
+  // Row offsets inside a 32x32 tile: (r & 3) + 8 (r >> 2) + 4 fh.  Every option is a wave-uniform branch around a
+  // 16-element pass so the common cases stay straight-line.
+  const int ldc = g.ldc;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+    const bool n_ok = n < N;
+    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+      const size_t base = (size_t)mb * ldc + n;
+      int ok = 0;  // bit r set: element r is inside the problem
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ok |= (n_ok && mb + (r & 3) + 8 * (r >> 2) < Mend) ? (1 << r) : 0;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
+      if (g.act == 1) {
+        if (g.aux_out) {
+          float* q = g.aux_out + base;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = quick_gelu(v[r]);
+      } else if (g.act == 2) {
+        const float* q = g.aux_in + base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) v[r] *= quick_gelu_grad(q[((r & 3) + 8 * (r >> 2)) * ldc]);
+      }
+      if (g.residual) {
+        const float* q = g.residual + (size_t)mb * g.ldres + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) v[r] += q[((r & 3) + 8 * (r >> 2)) * g.ldres];
+      }
+      if (g.C) {
+        float* q = g.C + base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+      }
+      if (p.C16) {
+        _Float16* q = p.C16 + base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static int launch_f16(F16Params& p, hipStream_t stream) {
+  p.n_blocks_n = (p.a.N + BN - 1) / BN;
+  const int mb = (p.m_end - p.m_begin + BM - 1) / BM;
+  const size_t lds = 3 * (size_t)(BM * 64 + BN * 64);
+  static bool attr = false;
+  if (!attr && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
+  return launch_status();
+}
+
+// called from clipfs_gemm_nt when args->A_f16 is set
+int gemm_f16_dispatch(const clipfs_gemm_args& a, hipStream_t stream) {
+  F16Params p;
+  p.a = a;
+  p.A16 = reinterpret_cast<const _Float16*>(a.A_f16);
+  p.B16 = reinterpret_cast<const _Float16*>(a.B_planes);
+  p.C16 = reinterpret_cast<_Float16*>(a.C_f16);
+  p.m_begin = 0;
+  p.m_end = a.M;
+  static const int tile_cfg = getenv("CLIPFS_F16_TILE") ? atoi(getenv("CLIPFS_F16_TILE")) : 0;  // tuning aid
+  const bool lora_ok_256 = !a.lora_t || a.lora_seg_width % 128 == 0;
+  if (tile_cfg == 2) return launch_f16<64, 128>(p, stream);
+  if (tile_cfg == 1) return launch_f16<128, 128>(p, stream);
+  if (tile_cfg == 3 && lora_ok_256) return launch_f16<256, 128>(p, stream);
+  const int nbn = (a.N + 127) / 128;
+  // Few tiles: small tiles keep the CUs busy.  Otherwise 256x128 tiles on the rows that fill whole rounds of
+  // 512 workgroup slots (2 per CU), and the leftover rows in 64-row tiles behind them.
+  if ((long)((a.M + 255) / 256) * nbn < 512) {
+    return ((long)((a.M + 127) / 128) * nbn >= 512) ? launch_f16<128, 128>(p, stream) : launch_f16<64, 128>(p, stream);
+  }
+  const int mb = (a.M + 255) / 256;
+  const long tiles = (long)mb * nbn;
+  const long over = tiles % 512;  // tiles beyond the last full round of 512 slots
+  int peel_blocks = 0;
+  if (tiles > 512 && over > 0 && over * 8 <= 512) peel_blocks = (int)((over + nbn - 1) / nbn);
+  p.m_end = (mb - peel_blocks) * 256;
+  if (peel_blocks == 0 || p.m_end >= a.M || p.m_end <= 0) {
+    p.m_end = a.M;
+    return launch_f16<256, 128>(p, stream);
+  }
+  CLIPFS_CHECK((launch_f16<256, 128>(p, stream)));
+  p.m_begin = p.m_end;
+  p.m_end = a.M;
+  return launch_f16<64, 128>(p, stream);
+}
+
+}  // namespace clipfs

@@ -100,3 +100,25 @@ def bf16_bench():
 
 if __name__ == "__main__" and "--bf16" in sys.argv:
     bf16_bench()
+
+
+def f16_bench():
+    """cfg-5 (ViT-L/14, 128 images x 257 tokens) GEMM shapes: fp32-A/f16-B kernel vs the f16 x f16 kernel."""
+    shapes = [("qkv", 32896, 3072, 1024), ("out", 32896, 1024, 1024), ("fc", 32896, 4096, 1024),
+              ("proj", 32896, 1024, 4096), ("dqkv", 32896, 1024, 3072), ("sq8192", 8192, 8192, 8192)]
+    for name, M, N, K in shapes:
+        a = torch.randn(M, K, device=dev)
+        b = torch.randn(N, K, device=dev) * K ** -0.5
+        out = torch.empty(M, N, device=dev)
+        out16 = torch.empty(M, N, device=dev, dtype=torch.float16)
+        a16, b16 = a.half(), ops.to_f16(b)
+        t0 = timeit(lambda: ops.gemm_nt(a, b, out, b_planes=b16))
+        t1 = timeit(lambda: ops.gemm_nt(None, b, out, b_planes=b16, a16=a16))
+        t2 = timeit(lambda: ops.gemm_nt(None, b, out, b_planes=b16, a16=a16, out16=out16))
+        fl = 2 * M * N * K
+        print(f"gemm {name:7s} f32A {t0*1e6:8.1f} us {fl/t0/1e12:7.1f} TF | f16A {t1*1e6:8.1f} us {fl/t1/1e12:7.1f} TF "
+              f"| +C16 {t2*1e6:8.1f} us {fl/t2/1e12:7.1f} TF", flush=True)
+
+
+if __name__ == "__main__" and "--f16" in sys.argv:
+    f16_bench()

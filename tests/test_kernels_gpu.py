@@ -389,3 +389,49 @@ def test_gemm_f16_mode(dev):
     rounded = a.float().half().double() @ w.float().half().double().t()
     _close(out, rounded, 2e-5, "f16 gemm vs rounded operands")
     assert (out.double().cpu() - a @ w.t()).abs().max().item() < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,lora_r,act", [(300, 256, 64, 0, 0), (2056, 1024, 1024, 16, 0), (1100, 512, 2048, 4, 1),
+                                               (33000, 1024, 256, 0, 2), (700, 384, 128, 0, 0)])
+def test_gemm_f16_operands(M, N, K, lora_r, act):
+    """f16 x f16 kernel (cfg-5 storage mode): both operands f16 in HBM, fp32 accumulate; f16 products are exact in
+    fp32, so against an fp32 matmul of the same rounded operands only the summation order differs (tolerance 2e-5
+    relative to the row scale); the f16 output copy is the fp32 result rounded once (2^-11 relative)."""
+    from clipfs import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    a16, w16 = a.half(), ops.to_f16(w)
+    kw = {}
+    ref = a16.float() @ w16.float().T + bias
+    if lora_r:
+        segw = N // 2 if N % 256 == 0 else N
+        nseg = N // segw
+        t = torch.randn(M, nseg * lora_r, generator=g).cuda()
+        lb = (torch.randn(N, lora_r, generator=g) * 0.1).cuda()
+        kw = dict(lora_t=t, lora_b=lb, lora_seg_width=segw, lora_scale=0.25)
+        t16 = t.half().float().view(M, nseg, lora_r)
+        lb16 = (0.25 * lb).half().float()
+        for sgi in range(nseg):
+            ref[:, sgi * segw:(sgi + 1) * segw] += t16[:, sgi] @ lb16[sgi * segw:(sgi + 1) * segw].T
+    aux_in = aux_out = pre = None
+    if act == 1:
+        aux_out = torch.empty(M, N, device="cuda")
+        pre = ref.clone()
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif act == 2:
+        aux_in = torch.randn(M, N, generator=g).cuda()
+        sg = torch.sigmoid(1.702 * aux_in)
+        ref = ref * (sg * (1 + 1.702 * aux_in * (1 - sg)))
+    ref = ref + res
+    out16 = torch.empty(M, N, device="cuda", dtype=torch.float16)
+    out = ops.gemm_nt(None, w, bias=bias, residual=res, act=act, aux_out=aux_out, aux_in=aux_in, b_planes=w16, a16=a16,
+                      out16=out16, **kw)
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-5 * scale + 1e-5
+    assert (out16.float() - ref).abs().max().item() <= 1e-3 * scale
+    if act == 1:
+        assert (aux_out - pre).abs().max().item() <= 2e-5 * pre.abs().max().item() + 1e-5
