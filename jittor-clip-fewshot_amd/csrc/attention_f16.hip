@@ -1,0 +1,415 @@
+// MFMA attention for the fp16 storage mode (cfg-5: ViT-L/14, L = 257, head_dim 64, non-causal): the same function
+// as attention.hip (jclip/mha.py:55-83,439-458) with the two contractions on v_mfma_f32_32x32x16_f16, softmax
+// statistics and every accumulator in fp32.
+//
+// One workgroup per (batch, head).  The head's K, V (forward / dQ pass) or Q, dO (dK/dV pass) are converted to f16
+// once and kept in LDS in two images: row-major [token][64] for the contraction over the feature axis (lane =
+// token row, ds_read_b128) and transposed [64][token] for the contraction over the token axis (ds_read_b64).
+// A wave owns a tile of 32 "own" tokens whose operands stay in registers and walks over the 32-token tiles of the
+// other side.
+//
+// The layout trick that keeps softmax in registers: scores are computed TRANSPOSED, S^T[key][query] = K Q^T, so the
+// MFMA result layout (column = lane & 31, 16 rows per lane) gives every lane 16 keys of ONE query.  Row max / row
+// sum are then in-lane reductions plus one exchange with lane ^ 32, the running (m, l) and the rescale factor are
+// per-lane scalars, and P^T is -- without any data movement -- exactly the B operand of the next product
+// O^T[d][query] += V^T[d][key] P^T[key][query]  (the MFMA sums over k in any order as long as A and B agree, so the
+// A operand reads V^T at the keys the lane's registers hold: 4 consecutive keys at +0 and 4 at +8).
+#include "common.h"
+
+namespace clipfs {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AF_HD = 64;
+constexpr int AF_MAXL = 288;        // 9 tiles of 32 tokens
+constexpr int AF_ROW = 72;          // row-major image: halves per token row (64 + 8 pad: conflict-free ds_read_b128)
+constexpr int AF_TP = 292;          // transposed image: halves per feature row (conflict-free ds_read_b64)
+constexpr float AF_LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ f16x8 cvt8(const f32x4& a, const f32x4& b) {
+  f16x8 h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = (_Float16)a[j];
+    h[4 + j] = (_Float16)b[j];
+  }
+  return h;
+}
+
+// Stage `L` token rows (fp32, 64 features at `src`, row stride ld) as f16 into a row-major image and/or a transposed
+// image; tokens [L, Lp) are zero-filled so masked lanes multiply finite values.
+__device__ __forceinline__ void stage_head(const float* __restrict__ src, size_t ld, int L, int Lp, _Float16* rowm,
+                                           _Float16* tr) {
+  if (rowm)  // feature chunk fastest: coalesced global reads, one ds_write_b128 per (token, chunk)
+    for (int idx = threadIdx.x; idx < Lp * 8; idx += (int)blockDim.x) {
+      const int tok = idx >> 3, c = idx & 7;
+      f16x8 h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
+      if (tok < L) {
+        const float* p = src + (size_t)tok * ld + 8 * c;
+        h = cvt8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+      }
+      *reinterpret_cast<f16x8*>(rowm + tok * AF_ROW + 8 * c) = h;
+    }
+  if (tr)  // token fastest: the eight ds_write_b16 of a lane group go to consecutive halves of one feature row
+    for (int idx = threadIdx.x; idx < Lp * 8; idx += (int)blockDim.x) {
+      const int c = idx / Lp, tok = idx - c * Lp;
+      f16x8 h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
+      if (tok < L) {
+        const float* p = src + (size_t)tok * ld + 8 * c;
+        h = cvt8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tr[(8 * c + j) * AF_TP + tok] = h[j];
+    }
+}
+
+// The wave's own 32 rows as MFMA operands: frag[s] = row (t0 + lane & 31), features 16 s + 8 (lane >> 5) .. + 7.
+__device__ __forceinline__ void load_own(const float* __restrict__ src, size_t ld, int t0, int L, int lane, f16x8 (&frag)[4]) {
+  const float* p = src + (size_t)min(t0 + (lane & 31), L - 1) * ld + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    frag[s] = cvt8(*reinterpret_cast<const f32x4*>(p + 16 * s), *reinterpret_cast<const f32x4*>(p + 16 * s + 4));
+}
+
+// acc[tile rows = other-side tokens t0.. (register index)][cols = own tokens (lane)] = other_rowmajor . own^T
+__device__ __forceinline__ f32x16 scores_T(const _Float16* rowm, int t0, int lane, const f16x8 (&own)[4]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const _Float16* p = rowm + (t0 + (lane & 31)) * AF_ROW + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(p + 16 * s), own[s], acc, 0, 0, 0);
+  return acc;
+}
+
+// A operand of the token-axis contraction for key slice u (16 tokens) of the tile at t0: feature row (dt*32 + lane&31),
+// tokens t0 + 16 u + 4 fh + {0..3} and + 8 + {0..3}  (the tokens registers 8u .. 8u+7 of the lane hold).
+__device__ __forceinline__ f16x8 load_T(const _Float16* tr, int dt, int t0, int u, int lane) {
+  const _Float16* p = tr + (dt * 32 + (lane & 31)) * AF_TP + t0 + 16 * u + 4 * (lane >> 5);
+  const f16x4 lo = *reinterpret_cast<const f16x4*>(p);
+  const f16x4 hi = *reinterpret_cast<const f16x4*>(p + 8);
+  f16x8 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = lo[j];
+    v[4 + j] = hi[j];
+  }
+  return v;
+}
+
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// ---------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                float* __restrict__ lse, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int Lp = (L + 31) & ~31;
+  _Float16* sK = reinterpret_cast<_Float16*>(smem_raw);  // [Lp][AF_ROW]
+  _Float16* sVt = sK + Lp * AF_ROW;                       // [64][AF_TP]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = (int)blockDim.x >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = H * AF_HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
+  stage_head(q0 + d, ld, L, Lp, sK, nullptr);
+  stage_head(q0 + 2 * d, ld, L, Lp, nullptr, sVt);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  const float c = 0.125f * AF_LOG2E;  // scores in log2 units
+  for (int qt = wave; qt * 32 < L; qt += nw) {
+    const int q_tok = qt * 32 + fr;
+    f16x8 qf[4];
+    load_own(q0, ld, qt * 32, L, lane, qf);
+    f32x16 o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < L; k0 += 32) {
+      f32x16 s = scores_T(sK, k0, lane, qf);
+      float mt = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        s[r] = key < L ? s[r] * c : -INFINITY;
+        mt = fmaxf(mt, s[r]);
+      }
+      mt = fmaxf(mt, xor32(mt));
+      const float mn = fmaxf(m, mt);
+      const float f = __builtin_amdgcn_exp2f(m - mn);
+      float ps = 0.f;
+      f16x8 pf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[r] - mn);
+        ps += p;
+        pf[r >> 3][r & 7] = (_Float16)p;
+      }
+      l = l * f + ps;
+      m = mn;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sVt, t, k0, u, lane), pf[u], o[t], 0, 0, 0);
+      }
+    }
+    l += xor32(l);
+    const float inv = 1.f / l;
+    if (q_tok < L) {
+      float* op = out + ((size_t)b * L + q_tok) * d + h * AF_HD + 4 * fh;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g4 + j] * inv;
+          *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g4) = v;
+        }
+      if (lse && fh == 0) lse[((size_t)b * H + h) * L + q_tok] = (m + log2f(l)) * (1.f / AF_LOG2E);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward, pass 1: dQ (and D_i = dO_i . O_i for pass 2).  Own side = queries; K (both images) and V in LDS.
+//   S^T = K Q^T ; P^T = exp(S^T c - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - D) / 8 ; dQ^T += K^T dS^T
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* __restrict__ qkv,
+                                                                  const float* __restrict__ dout,
+                                                                  const float* __restrict__ out,
+                                                                  const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                                  float* __restrict__ Dbuf, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int Lp = (L + 31) & ~31;
+  _Float16* sK = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* sV = sK + Lp * AF_ROW;
+  _Float16* sKt = sV + Lp * AF_ROW;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = (int)blockDim.x >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = H * AF_HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
+  stage_head(q0 + d, ld, L, Lp, sK, sKt);
+  stage_head(q0 + 2 * d, ld, L, Lp, sV, nullptr);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  const float c = 0.125f * AF_LOG2E;
+  for (int qt = wave; qt * 32 < L; qt += nw) {
+    const int q_tok = qt * 32 + fr, q_cl = min(q_tok, L - 1);
+    f16x8 qf[4], gf[4];
+    load_own(q0, ld, qt * 32, L, lane, qf);
+    float Di = 0.f;
+    {
+      const float* gp = dout + ((size_t)b * L + q_cl) * d + h * AF_HD + 8 * fh;
+      const float* op = out + ((size_t)b * L + q_cl) * d + h * AF_HD + 8 * fh;
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + 16 * sidx), g1 = *reinterpret_cast<const f32x4*>(gp + 16 * sidx + 4);
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(op + 16 * sidx), o1 = *reinterpret_cast<const f32x4*>(op + 16 * sidx + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Di += g0[j] * o0[j] + g1[j] * o1[j];
+        gf[sidx] = cvt8(g0, g1);
+      }
+      Di += xor32(Di);
+    }
+    const float lse2 = lse[((size_t)b * H + h) * L + q_cl] * AF_LOG2E;
+    if (q_tok < L && fh == 0) Dbuf[((size_t)b * H + h) * L + q_tok] = Di;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int k0 = 0; k0 < L; k0 += 32) {
+      const f32x16 s = scores_T(sK, k0, lane, qf);
+      const f32x16 dp = scores_T(sV, k0, lane, gf);
+      f16x8 dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const float p = key < L ? __builtin_amdgcn_exp2f(s[r] * c - lse2) : 0.f;
+        dsf[r >> 3][r & 7] = (_Float16)(p * (dp[r] - Di) * 0.125f);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sKt, t, k0, u, lane), dsf[u], acc[t], 0, 0, 0);
+    }
+    if (q_tok < L) {
+      float* op = dqkv + ((size_t)b * L + q_tok) * ld + h * AF_HD + 4 * fh;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[t][4 * g4 + j];
+          *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g4) = v;
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward, pass 2: dK, dV.  Own side = keys; Q and dO (both images each) plus lse and D in LDS.
+//   S = Q K^T ; P = exp(S c - lse) ; dP = dO V^T ; dS = P (dP - D) / 8 ; dV^T += dO^T P ; dK^T += Q^T dS
+// (rows of the MFMA result = queries, so lse and D vary with the register index: read as 4-float groups from LDS).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* __restrict__ qkv,
+                                                                   const float* __restrict__ dout,
+                                                                   const float* __restrict__ lse,
+                                                                   const float* __restrict__ Dbuf,
+                                                                   float* __restrict__ dqkv, int L, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int Lp = (L + 31) & ~31;
+  _Float16* sQ = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* sG = sQ + Lp * AF_ROW;
+  _Float16* sQt = sG + Lp * AF_ROW;
+  _Float16* sGt = sQt + 64 * AF_TP;
+  float* sLse = reinterpret_cast<float*>(sGt + 64 * AF_TP);  // [Lp] in log2 units
+  float* sD = sLse + Lp;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = (int)blockDim.x >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = H * AF_HD;
+  const size_t ld = (size_t)3 * d;
+  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
+  stage_head(q0, ld, L, Lp, sQ, sQt);
+  stage_head(dout + (size_t)b * L * d + (size_t)h * AF_HD, (size_t)d, L, Lp, sG, sGt);
+  for (int i = threadIdx.x; i < Lp; i += (int)blockDim.x) {
+    sLse[i] = i < L ? lse[((size_t)b * H + h) * L + i] * AF_LOG2E : 0.f;
+    sD[i] = i < L ? Dbuf[((size_t)b * H + h) * L + i] : 0.f;
+  }
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  const float c = 0.125f * AF_LOG2E;
+  for (int kt = wave; kt * 32 < L; kt += nw) {
+    const int k_tok = kt * 32 + fr;
+    f16x8 kf[4], vf[4];
+    load_own(q0 + d, ld, kt * 32, L, lane, kf);
+    load_own(q0 + 2 * d, ld, kt * 32, L, lane, vf);
+    f32x16 av[2], ak[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        av[t][r] = 0.f;
+        ak[t][r] = 0.f;
+      }
+    for (int i0 = 0; i0 < L; i0 += 32) {
+      const f32x16 s = scores_T(sQ, i0, lane, kf);
+      const f32x16 dp = scores_T(sG, i0, lane, vf);
+      f16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + i0 + 8 * g4 + 4 * fh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + i0 + 8 * g4 + 4 * fh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const int qi = i0 + 8 * g4 + 4 * fh + j;
+          const float p = qi < L ? __builtin_amdgcn_exp2f(s[r] * c - l4[j]) : 0.f;
+          pf[r >> 3][r & 7] = (_Float16)p;
+          dsf[r >> 3][r & 7] = (_Float16)(p * (dp[r] - d4[j]) * 0.125f);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          av[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sGt, t, i0, u, lane), pf[u], av[t], 0, 0, 0);
+          ak[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sQt, t, i0, u, lane), dsf[u], ak[t], 0, 0, 0);
+        }
+    }
+    if (k_tok < L) {
+      float* kp = dqkv + ((size_t)b * L + k_tok) * ld + d + h * AF_HD + 4 * fh;
+      float* vp = kp + d;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 k4, v4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            k4[j] = ak[t][4 * g4 + j];
+            v4[j] = av[t][4 * g4 + j];
+          }
+          *reinterpret_cast<f32x4*>(kp + 32 * t + 8 * g4) = k4;
+          *reinterpret_cast<f32x4*>(vp + 32 * t + 8 * g4) = v4;
+        }
+    }
+  }
+}
+
+static size_t af_lds_bytes(int L, int images_rowmajor, int images_transposed) {
+  const int Lp = (L + 31) & ~31;
+  return ((size_t)images_rowmajor * Lp * AF_ROW + (size_t)images_transposed * 64 * AF_TP) * sizeof(_Float16);
+}
+
+}  // namespace clipfs
+
+using namespace clipfs;
+
+static int check_af(const void* a, const void* b, int batch, int seq, int heads) {
+  CLIPFS_REQUIRE(a && b, "attention_f16: null pointer");
+  CLIPFS_REQUIRE(batch > 0 && heads > 0 && seq > 0 && seq <= AF_MAXL, "attention_f16: seq %d outside 1..%d", seq, AF_MAXL);
+  return CLIPFS_OK;
+}
+
+extern "C" int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads,
+                                        void* stream) {
+  CLIPFS_CHECK(check_af(qkv, out, batch, seq, heads));
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attention_f16_fwd_kernel, dim3(batch * heads), dim3(320), af_lds_bytes(seq, 1, 1),
+                     (hipStream_t)stream, qkv, out, lse, seq, heads);
+  return launch_status();
+}
+
+extern "C" int clipfs_attention_f16_bwd(const float* qkv, const float* dout, const float* out, const float* lse,
+                                        float* dqkv, float* work, int batch, int seq, int heads, void* stream) {
+  CLIPFS_CHECK(check_af(qkv, dqkv, batch, seq, heads));
+  CLIPFS_REQUIRE(dout && out && lse && work, "attention_f16_bwd: null pointer");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_q_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_kv_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const int tiles = (seq + 31) / 32;
+  const int threads = 64 * (tiles < 9 ? tiles : 9);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attention_f16_bwd_q_kernel, dim3(batch * heads), dim3(threads), af_lds_bytes(seq, 2, 1), st, qkv,
+                     dout, out, lse, dqkv, work, seq, heads);
+  CLIPFS_CHECK(launch_status());
+  const size_t lds_kv = af_lds_bytes(seq, 2, 2) + 2 * (size_t)((seq + 31) & ~31) * sizeof(float);
+  hipLaunchKernelGGL(attention_f16_bwd_kv_kernel, dim3(batch * heads), dim3(threads), lds_kv, st, qkv, dout, lse, work,
+                     dqkv, seq, heads);
+  return launch_status();
+}

@@ -36,7 +36,7 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
 }
 
 struct ScratchLayout {
-  size_t h, big, b3, b1, dt, work, gemm_ws, gemm_ws_floats, total;
+  size_t h, big, b3, b1, dt, work, gemm_ws, gemm_ws_floats, a16, c16, total;
 };
 
 static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
@@ -58,6 +58,9 @@ static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
     ws = w > ws ? w : ws;
   }
   S.gemm_ws = o; S.gemm_ws_floats = ws; o += al4(ws);
+  // fp16 storage mode (weight_format 2): f16 images of the GEMM operands, M x 4d halves each
+  S.a16 = o; o += t->weight_format == 2 ? al4(M * 2 * d) : 0;
+  S.c16 = o; o += t->weight_format == 2 ? al4(M * 2 * d) : 0;
   S.total = o;
   return S;
 }
@@ -67,16 +70,32 @@ static int check_tower(const clipfs_tower* t, int batch) {
   CLIPFS_REQUIRE(batch > 0 && t->layers > 0 && t->seq > 0 && t->heads > 0 && t->width == t->heads * 64,
                  "tower: width %d must be heads %d * 64", t->width, t->heads);
   CLIPFS_REQUIRE(t->lora_r >= 0 && t->lora_r <= 16, "tower: lora rank %d unsupported", t->lora_r);
+  if (t->weight_format == 2)  // fp16 storage mode chains f16 results between GEMMs: every block needs all its f16 weights
+    for (int l = 0; l < t->layers; ++l) {
+      const clipfs_block& b = t->blocks[l];
+      CLIPFS_REQUIRE(b.w_qkv_p && b.w_o_p && b.w_fc_p && b.w_pr_p, "tower: block %d lacks f16 weight copies", l);
+    }
   return CLIPFS_OK;
+}
+
+// fp16 storage mode runs the medium-sequence, non-causal attention (ViT-L/14: 257 tokens) on the f16 MFMA kernels
+static inline bool f16_attention(const clipfs_tower* t) {
+  return t->weight_format == 2 && !t->causal && t->seq > 96 && t->seq <= 288;
 }
 
 static thread_local float* g_ws = nullptr;  // split-K scratch of the tower call in progress (its scratch buffer)
 static thread_local size_t g_ws_floats = 0;
 static thread_local int g_b_format = 0;  // format of the blocks' 16-bit weight copies for the call in progress
+static thread_local void* g_a16 = nullptr;  // fp16 mode: f16 image of the A operand (converted per GEMM)
+static thread_local void* g_c16 = nullptr;  // fp16 mode: f16 output handed from one GEMM to the next
 
+enum GemmChain { CHAIN_NONE = 0, CHAIN_OUT16 = 1, CHAIN_IN16 = 2 };
+
+// chain: CHAIN_OUT16 = the result is only the next GEMM's A operand: in fp16 mode write it as f16 alone;
+//        CHAIN_IN16  = A is the previous GEMM's CHAIN_OUT16 result.
 static int gemm(const float* A, const float* B, const void* Bp, float* C, int M, int N, int K, const float* bias,
                 const float* res, int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r,
-                int nseg, int segw, float lscale, hipStream_t st) {
+                int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE) {
   clipfs_gemm_args a = {};
   a.B_planes = Bp;
   a.b_format = g_b_format;
@@ -87,6 +106,18 @@ static int gemm(const float* A, const float* B, const void* Bp, float* C, int M,
   a.bias = bias; a.residual = res; a.ldres = N;
   a.act = act; a.aux_out = aux_out; a.aux_in = aux_in;
   a.lora_t = lt; a.lora_b = lb; a.lora_r = r; a.lora_nseg = nseg; a.lora_seg_width = segw; a.lora_scale = lscale;
+  if (g_b_format == 2 && Bp && g_a16 && (K % 32) == 0 && (!lt || (segw % 128 == 0 && r <= 16))) {
+    if (chain & CHAIN_IN16) {
+      a.A_f16 = g_c16;
+    } else {
+      CLIPFS_CHECK(clipfs_convert_f16(A, g_a16, (size_t)M * K, st));
+      a.A_f16 = g_a16;
+    }
+    if (chain & CHAIN_OUT16) {
+      a.C_f16 = g_c16;
+      a.C = nullptr;
+    }
+  }
   return clipfs_gemm_nt(&a, st);
 }
 
@@ -115,6 +146,8 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
   g_ws = scratch + SC.gemm_ws;
   g_ws_floats = SC.gemm_ws_floats;
   g_b_format = t->weight_format;
+  g_a16 = t->weight_format == 2 ? scratch + SC.a16 : nullptr;
+  g_c16 = t->weight_format == 2 ? scratch + SC.c16 : nullptr;
   const uint64_t seed = train ? t->dropout_seed : 0;  // dropout only when training (is_training(), :298)
   if (train) {
     hipError_t e = hipMemcpyAsync(saved + SL.x_in, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -141,7 +174,10 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
       CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, st));
     CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
                       b.lora_b_qkv, r, 3, d, t->lora_scale, st));
-    CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
+    if (f16_attention(t))
+      CLIPFS_CHECK(clipfs_attention_f16_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, st));
+    else
+      CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
     if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, st));
     CLIPFS_CHECK(gemm(att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
                       1, d, t->lora_scale, st));
@@ -150,9 +186,9 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
                                       train ? sv + SL.stat2 + M : nullptr, M, d, 1e-5f, st));
     float* gbuf = scratch + SC.big;
     CLIPFS_CHECK(gemm(h2, b.w_fc, b.w_fc_p, gbuf, M, 4 * d, d, b.b_fc, nullptr, 1, train ? sv + SL.u : nullptr, nullptr, nullptr,
-                      nullptr, 0, 0, 0, 0.f, st));
+                      nullptr, 0, 0, 0, 0.f, st, CHAIN_OUT16));
     CLIPFS_CHECK(gemm(gbuf, b.w_pr, b.w_pr_p, x_next, M, d, 4 * d, b.b_pr, x_mid, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
-                      0.f, st));
+                      0.f, st, CHAIN_IN16));
   }
   return CLIPFS_OK;
 }
@@ -168,11 +204,15 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
   g_ws = scratch + SC.gemm_ws;
   g_ws_floats = SC.gemm_ws_floats;
   g_b_format = t->weight_format;
+  g_a16 = t->weight_format == 2 ? scratch + SC.a16 : nullptr;
+  g_c16 = t->weight_format == 2 ? scratch + SC.c16 : nullptr;
   const uint64_t seed = t->dropout_seed;
   for (int l = t->layers - 1; l >= 0; --l) {
     const clipfs_block& b = t->blocks[l];
     const float* sv = saved + (size_t)l * SL.total;
     CLIPFS_REQUIRE(b.w_pr_t && b.w_fc_t && b.w_o_t && b.w_qkv_t, "tower_bwd: block %d lacks transposed weights", l);
+    CLIPFS_REQUIRE(t->weight_format != 2 || (b.w_pr_t_p && b.w_fc_t_p && b.w_o_t_p && b.w_qkv_t_p),
+                   "tower_bwd: block %d lacks f16 copies of the transposed weights", l);
     const unsigned qkv_mask = b.lora_a_qkv ? (b.lora_mask & 7u) : 0u;
     const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
     const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
@@ -184,9 +224,9 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     float* work = scratch + SC.work;
     // MLP: du = (dx Wpr) * gelu'(u) ; dh2 = du Wfc ; dx += LN2'(dh2)
     CLIPFS_CHECK(gemm(dx, b.w_pr_t, b.w_pr_t_p, du, M, 4 * d, d, nullptr, nullptr, 2, nullptr, sv + SL.u, nullptr, nullptr, 0, 0, 0,
-                      0.f, st));
+                      0.f, st, CHAIN_OUT16));
     CLIPFS_CHECK(gemm(du, b.w_fc_t, b.w_fc_t_p, dh, M, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
-                      st));
+                      st, CHAIN_IN16));
     CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, d, M, d,
                                       st));
     // attention output projection
@@ -198,8 +238,11 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
                                    datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, work, st));
     }
     // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
-    CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
-                                      t->causal, st));
+    if (f16_attention(t))
+      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads, st));
+    else
+      CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
+                                        t->causal, st));
     const bool need_dx = !(l == 0 && stop_at_input);
     if (need_dx)
       CLIPFS_CHECK(gemm(dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,

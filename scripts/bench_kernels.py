@@ -122,3 +122,23 @@ def f16_bench():
 
 if __name__ == "__main__" and "--f16" in sys.argv:
     f16_bench()
+
+
+def attn16_bench():
+    """cfg-5 attention (128 images x 16 heads x 257 tokens): fp32 LDS-resident kernels vs the f16 MFMA kernels."""
+    B, H, L = 128, 16, 257
+    qkv = torch.randn(B * L, 3 * H * 64, device=dev)
+    dout = torch.randn(B * L, H * 64, device=dev)
+    out, lse = ops.attention_fwd(qkv, B, L, H, False, want_lse=True)
+    o16, l16 = ops.attention_f16_fwd(qkv, B, L, H)
+    fl = 4 * L * L * 64 * B * H
+    t0 = timeit(lambda: ops.attention_fwd(qkv, B, L, H, False, want_lse=True))
+    t1 = timeit(lambda: ops.attention_f16_fwd(qkv, B, L, H))
+    print(f"attn fwd  fp32 {t0*1e6:8.1f} us {fl/t0/1e12:6.1f} TF | f16 mfma {t1*1e6:8.1f} us {fl/t1/1e12:6.1f} TF", flush=True)
+    t0 = timeit(lambda: ops.attention_bwd(qkv, dout, B, L, H, False, out=out, lse=lse))
+    t1 = timeit(lambda: ops.attention_f16_bwd(qkv, dout, o16, l16, B, L, H))
+    print(f"attn bwd  fp32 {t0*1e6:8.1f} us {2.5*fl/t0/1e12:6.1f} TF | f16 mfma {t1*1e6:8.1f} us {2.5*fl/t1/1e12:6.1f} TF", flush=True)
+
+
+if __name__ == "__main__" and "--attn16" in sys.argv:
+    attn16_bench()
