@@ -5,6 +5,8 @@
 // and the backward is three skinny products that each read their big operand exactly once.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace clipfs {
 
 constexpr int LORA_MAX_CHUNKS = 8;  // width <= 2048
@@ -253,6 +255,24 @@ static inline int lora_slice_rows(int rows) {
   return r;
 }
 
+// lora_mfma.hip
+bool lora_mfma_ok(int width, int segw, int r, int nseg);
+int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
+                   float p, uint64_t seed, uint32_t stream_base, hipStream_t st);
+int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
+                  float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
+                  float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st,
+                  void (*reduce)(const float*, float*, size_t, int, float, hipStream_t));
+
+static void launch_reduce_slices(const float* part, float* out, size_t n, int slices, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, part, out, n, slices, scale);
+}
+
+static bool use_lora_mfma() {
+  static const int cfg = getenv("CLIPFS_LORA_MFMA") ? atoi(getenv("CLIPFS_LORA_MFMA")) : 1;  // 0: scalar kernels (A/B aid)
+  return cfg != 0;
+}
+
 }  // namespace clipfs
 
 using namespace clipfs;
@@ -264,6 +284,8 @@ extern "C" int clipfs_lora_down(const float* x, const float* A, float* t, int ro
   CLIPFS_REQUIRE(r > 0 && r <= 64 && nseg > 0 && nseg <= 4 && nseg * r <= LORA_MAX_OUT, "lora_down: r %d nseg %d unsupported", r, nseg);
   CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_down: dropout p %f out of range", (double)p);
   CLIPFS_REQUIRE(aligned16(x) && aligned16(A), "lora_down: misaligned pointer");
+  if (use_lora_mfma() && lora_mfma_ok(width, width, r, nseg))
+    return lora_down_mfma(x, A, t, rows, width, r, nseg, seg_mask, p, seed, stream_base, (hipStream_t)stream);
   hipLaunchKernelGGL(lora_down_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, A, t, rows, width, r,
                      nseg, seg_mask, p, seed, stream_base);
   return launch_status();
@@ -334,6 +356,9 @@ extern "C" int clipfs_lora_bwd(const float* dy, const float* x, const float* t, 
   CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_bwd: dropout p out of range");
   CLIPFS_REQUIRE(aligned16(x) && aligned16(A) && aligned16(work) && (!dx || aligned16(dx)), "lora_bwd: misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (use_lora_mfma() && lora_mfma_ok(width, segw, r, nseg) && aligned16(dy) && aligned16(dx ? dx : x))
+    return lora_bwd_mfma(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base,
+                         work, st, launch_reduce_slices);
 #define CLIPFS_LORA_CASE(RR)                                                                                       \
   case RR:                                                                                                         \
     return lora_bwd_r<RR>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, nseg, seg_mask, scale, p, seed,       \

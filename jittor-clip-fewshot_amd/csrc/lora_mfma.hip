@@ -1,0 +1,426 @@
+// Rank-r LoRA products on the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32: the fp32 MFMA of the dense GEMMs
+// in its 16x16 shape, whose N = 16 fits ranks up to 16).  Same five products, same Philox dropout stream and same
+// results (up to summation order) as the one-wave-per-row kernels in lora.hip, which remain for shapes outside
+// r <= 16 / width % 64 == 0.  At r = 16 (cfg-5) the scalar kernels spend ~50 wave reductions per row; here every
+// product is a tall-skinny MFMA GEMM whose big operand is read once with 16-byte loads:
+//
+//   down  t[m, s r + j]   = sum_k drop_s(x)[m, k] A[s r + j, k]          A-operand = x rows, B-operand = A rows
+//   dt    dt[m, s r + j]  = scale sum_n dy[m, s w + n] B[s w + n, j]
+//   dB    dB[n, j]       += scale sum_m dy[m, n] t[m, seg(n) r + j]      reduction over rows: K index = row
+//   dA    dA[s r + j, k] += sum_m dt[m, s r + j] drop_s(x)[m, k]
+//   dx    dx[m, k]       += sum_s dropscale_s(m, k) sum_j dt[m, s r + j] A[s r + j, k]
+//
+// MFMA 16x16x4 layouts: A operand lane l = A[i = l & 15][k = l >> 4], B operand lane l = B[k = l >> 4][j = l & 15],
+// result lane l = D[i = 4 (l >> 4) + v][j = l & 15], v = 0..3.  The k (and, for dB/dA/dx, the column) assignment is
+// free as long as both operands agree, so a lane always loads FOUR CONSECUTIVE floats (one float4 = one Philox call
+// = 4 dropout multipliers) and feeds them to four successive MFMAs.
+#include "common.h"
+
+namespace clipfs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 zero4() {
+  f32x4 z;
+  z[0] = z[1] = z[2] = z[3] = 0.f;
+  return z;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Sum the four waves' partial accumulators (the waves of a block split the reduction axis) through LDS; wave 0 gets
+// the total.  red: [4 waves][NACC][64 lanes] f32x4.
+template <int NACC>
+__device__ __forceinline__ void block_sum4(f32x4 (&acc)[NACC], f32x4* red, int wave, int lane) {
+  if (wave != 0) {
+#pragma unroll
+    for (int s = 0; s < NACC; ++s) red[((wave - 1) * NACC + s) * 64 + lane] = acc[s];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int s = 0; s < NACC; ++s) acc[s] += red[(w * NACC + s) * 64 + lane];
+  }
+}
+
+// t = drop(x) A^T.  One block per 16 rows; its 4 waves take a quarter of the columns each (rows / 16 waves alone
+// would leave ~2 waves per SIMD).
+template <int NSEG>
+__global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __restrict__ x, const float* __restrict__ A,
+                                                             float* __restrict__ t, int rows, int width, int r,
+                                                             unsigned seg_mask, float p, uint64_t seed,
+                                                             uint32_t stream_base) {
+  __shared__ f32x4 red[3 * NSEG * 64];
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 16;
+  const int m = min(row0 + li, rows - 1);
+  const bool drop = p > 0.f && seed != 0;
+  const uint32_t thr = dropout_threshold(p);
+  const float inv_keep = 1.f / (1.f - p);
+  const float* xr = x + (size_t)m * width + 4 * kg;
+  const float* ar = A + (size_t)min(li, r - 1) * width + 4 * kg;
+  f32x4 acc[NSEG];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) acc[s] = zero4();
+  const int cw = width >> 2;  // columns per wave (width % 64 == 0)
+  const int cend = (wave + 1) * cw;
+  for (int c0 = wave * cw; c0 < cend; c0 += 64) {  // 4 steps of 16 columns, loads first
+    f32x4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cu = c0 + 16 * u;
+      xv[u] = ld4(xr + min(cu, cend - 16));
+      if (cu >= cend) xv[u] = zero4();
+    }
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+      if (!((seg_mask >> s) & 1u)) continue;
+      f32x4 wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wv[u] = ld4(ar + (size_t)s * r * width + min(c0 + 16 * u, cend - 16));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 xs = xv[u];
+        if (drop) {
+          const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)m, (uint32_t)(((c0 + 16 * u) >> 2) + kg), thr, inv_keep);
+          xs[0] *= mk.x;
+          xs[1] *= mk.y;
+          xs[2] *= mk.z;
+          xs[3] *= mk.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s] = mfma16(xs[e], wv[u][e], acc[s]);
+      }
+    }
+  }
+  block_sum4<NSEG>(acc, red, wave, lane);
+  if (wave == 0 && li < r) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int mo = row0 + 4 * kg + v;
+      if (mo < rows) {
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) t[(size_t)mo * (NSEG * r) + s * r + li] = ((seg_mask >> s) & 1u) ? acc[s][v] : 0.f;
+      }
+    }
+  }
+}
+
+// dt = scale * dy_seg B_seg
+template <int NSEG>
+__global__ __launch_bounds__(256) void lora_dt_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ B,
+                                                           float* __restrict__ dt, int rows, int segw, int r,
+                                                           unsigned seg_mask, float scale) {
+  __shared__ f32x4 red[3 * NSEG * 64];
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 16;
+  const int m = min(row0 + li, rows - 1);
+  const int cw = segw >> 2;
+  const float* dr = dy + (size_t)m * NSEG * segw + 4 * kg;
+  const int jj = min(li, r - 1);
+  f32x4 acc[NSEG];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) acc[s] = zero4();
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    if (!((seg_mask >> s) & 1u)) continue;
+    const float* bs = B + ((size_t)s * segw + 4 * kg) * r + jj;
+    const int cend = (wave + 1) * cw;
+    for (int c0 = wave * cw; c0 < cend; c0 += 64) {
+      f32x4 g[4];
+      float bv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cu = min(c0 + 16 * u, cend - 16);
+        g[u] = ld4(dr + s * segw + cu);
+        if (c0 + 16 * u >= cend) g[u] = zero4();
+        const float* bp = bs + (size_t)cu * r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[u][e] = bp[e * r];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s] = mfma16(g[u][e], bv[u][e], acc[s]);
+    }
+  }
+  block_sum4<NSEG>(acc, red, wave, lane);
+  if (wave == 0 && li < r) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int mo = row0 + 4 * kg + v;
+      if (mo < rows) {
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) dt[(size_t)mo * (NSEG * r) + s * r + li] = scale * acc[s][v];
+      }
+    }
+  }
+}
+
+// dB partials: part[slice][n][j] = sum_{m in slice} dy[m, n] t[m, seg(n) r + j].  One wave per (64 columns, slice);
+// lane i owns columns n0 + 4 i + e of MFMA tile e.
+__global__ __launch_bounds__(256) void lora_db_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ t,
+                                                           float* __restrict__ part, int rows, int cols, int segw,
+                                                           int nseg, int r, int rows_per_slice) {
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (n0 >= cols) return;
+  const int slice = blockIdx.y;
+  const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
+  const int s = n0 / segw;
+  const int tw = nseg * r;
+  const float* dp = dy + n0 + 4 * li;
+  const float* tp = t + s * r + min(li, r - 1);
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = zero4();
+
+  for (int mb = m0; mb < m1; mb += 16) {  // 4 steps of 4 rows, loads first
+    f32x4 g[4];
+    float tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = mb + 4 * u + kg;
+      const bool ok = m < m1;
+      const int mc = ok ? m : m1 - 1;
+      g[u] = ld4(dp + (size_t)mc * cols);
+      tv[u] = tp[(size_t)mc * tw];
+      if (!ok) {
+        g[u] = zero4();
+        tv[u] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = mfma16(g[u][e], tv[u], acc[e]);
+  }
+  if (li < r) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) part[((size_t)slice * cols + n0 + 4 * (4 * kg + v) + e) * r + li] = acc[e][v];
+  }
+}
+
+// dA partials: part[slice][s r + j][k] = sum_{m in slice} dt[m, s r + j] drop_s(x)[m, k].  One wave per (64 columns,
+// slice); lane i owns columns k0 + 4 i + e of MFMA tile e (so one Philox call covers the lane's float4 of x).
+template <int NSEG>
+__global__ __launch_bounds__(256) void lora_da_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dt,
+                                                           float* __restrict__ part, int rows, int width, int r,
+                                                           unsigned seg_mask, float p, uint64_t seed,
+                                                           uint32_t stream_base, int rows_per_slice) {
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (k0 >= width) return;
+  const int slice = blockIdx.y;
+  const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
+  const bool drop = p > 0.f && seed != 0;
+  const uint32_t thr = dropout_threshold(p);
+  const float inv_keep = 1.f / (1.f - p);
+  const int tw = NSEG * r;
+  const float* xp = x + k0 + 4 * li;
+  const float* dp = dt + min(li, r - 1);
+  const uint32_t c4 = (uint32_t)((k0 >> 2) + li);
+  f32x4 acc[NSEG][4];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[s][e] = zero4();
+  for (int mb = m0; mb < m1; mb += 8) {  // 2 steps of 4 rows, loads first
+    f32x4 xv[2];
+    float g[2][NSEG];
+    int mcs[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = mb + 4 * u + kg;
+      const bool ok = m < m1;
+      mcs[u] = ok ? m : m1 - 1;
+      xv[u] = ld4(xp + (size_t)mcs[u] * width);
+      if (!ok) xv[u] = zero4();
+#pragma unroll
+      for (int s = 0; s < NSEG; ++s) g[u][s] = dp[(size_t)mcs[u] * tw + s * r];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int s = 0; s < NSEG; ++s) {
+        if (!((seg_mask >> s) & 1u)) continue;
+        f32x4 xs = xv[u];
+        if (drop) {
+          const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)mcs[u], c4, thr, inv_keep);
+          xs[0] *= mk.x;
+          xs[1] *= mk.y;
+          xs[2] *= mk.z;
+          xs[3] *= mk.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[s][e] = mfma16(g[u][s], xs[e], acc[s][e]);
+      }
+  }
+  // result tile e: D[i = rank index 4 kg + v][j = li] <-> column k0 + 4 li + e: one float4 per (s, v)
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int j = 4 * kg + v;
+      if (j < r) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[s][e][v];
+        *reinterpret_cast<f32x4*>(part + ((size_t)slice * tw + s * r + j) * width + k0 + 4 * li) = o;
+      }
+    }
+}
+
+// dx[m, k] += sum_s dropscale_s(m, k) sum_j dt[m, s r + j] A[s r + j, k].  One block per 16 rows (its 4 waves take a
+// quarter of the columns each); per 16-column tile
+// the result D[i <-> column k0 + i][j <-> row] gives a lane 4 consecutive columns of one row: a float4 of dx.
+template <int NSEG, int RQ>  // RQ = ceil(r / 4) MFMA K-steps
+__global__ __launch_bounds__(256) void lora_dx_mfma_kernel(const float* __restrict__ dt, const float* __restrict__ A,
+                                                           float* __restrict__ dx, int rows, int width, int r,
+                                                           unsigned seg_mask, float p, uint64_t seed,
+                                                           uint32_t stream_base) {
+  const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
+  const int wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 16;
+  const int m = row0 + li;
+  const int mc = min(m, rows - 1);
+  const int cw = width >> 2;
+  const bool drop = p > 0.f && seed != 0;
+  const uint32_t thr = dropout_threshold(p);
+  const float inv_keep = 1.f / (1.f - p);
+  float dtv[NSEG][RQ];  // B operand: k = rank index 4 q + kg, j = row li
+  const float* ap[NSEG][RQ];
+  float amask[RQ];
+#pragma unroll
+  for (int q = 0; q < RQ; ++q) {
+    const int j = 4 * q + kg;
+    amask[q] = j < r ? 1.f : 0.f;
+#pragma unroll
+    for (int s = 0; s < NSEG; ++s) {
+      dtv[s][q] = dt[(size_t)mc * (NSEG * r) + s * r + min(j, r - 1)] * amask[q];
+      ap[s][q] = A + (size_t)(s * r + min(j, r - 1)) * width + li;
+    }
+  }
+  float* xr = dx + (size_t)mc * width + 4 * kg;
+  for (int k0 = wave * cw; k0 < (wave + 1) * cw; k0 += 32) {  // two 16-column tiles, loads first (cw % 32 == 0)
+    f32x4 tot[2];
+    float av[2][NSEG][RQ];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      tot[u] = ld4(xr + k0 + 16 * u);
+#pragma unroll
+      for (int s = 0; s < NSEG; ++s)
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) av[u][s][q] = ap[s][q][k0 + 16 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int s = 0; s < NSEG; ++s) {
+        if (!((seg_mask >> s) & 1u)) continue;
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) acc = mfma16(av[u][s][q], dtv[s][q], acc);
+        if (drop) {
+          const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)mc, (uint32_t)(((k0 + 16 * u) >> 2) + kg), thr, inv_keep);
+          acc[0] *= mk.x;
+          acc[1] *= mk.y;
+          acc[2] *= mk.z;
+          acc[3] *= mk.w;
+        }
+        tot[u] += acc;
+      }
+      if (m < rows) *reinterpret_cast<f32x4*>(xr + k0 + 16 * u) = tot[u];
+    }
+  }
+}
+
+// ---- host side (called from lora.hip) ---------------------------------------------------------------------
+
+bool lora_mfma_ok(int width, int segw, int r, int nseg) {
+  return r >= 1 && r <= 16 && (nseg == 1 || nseg == 3) && (width % 128) == 0 && (segw % 64) == 0;
+}
+
+// rows per reduction slice: enough slices to put ~6000 waves (column groups x slices) on the chip, few enough that
+// the partial sums stay small; never below 64 rows (the work buffer is sized for 64-row slices)
+static int lora_mfma_slice_rows(int rows, int col_groups) {
+  int sr = 2048;
+  while (sr > 64 && (long)col_groups * ((rows + sr - 1) / sr) < 6144) sr >>= 1;
+  return sr;
+}
+
+int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
+                   float p, uint64_t seed, uint32_t stream_base, hipStream_t st) {
+  const dim3 grid((rows + 15) / 16);
+  if (nseg == 1)
+    hipLaunchKernelGGL((lora_down_mfma_kernel<1>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base);
+  else
+    hipLaunchKernelGGL((lora_down_mfma_kernel<3>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base);
+  return launch_status();
+}
+
+template <int NSEG>
+static int lora_bwd_mfma_n(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
+                           float* dA, float* dB, float* dx, int rows, int width, int segw, int r, unsigned seg_mask,
+                           float scale, float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st,
+                           void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
+  const int cols = NSEG * segw;
+  const int sr_b = lora_mfma_slice_rows(rows, cols / 64), slices_b = (rows + sr_b - 1) / sr_b;
+  const int sr_a = lora_mfma_slice_rows(rows, width / 64), slices_a = (rows + sr_a - 1) / sr_a;
+  const dim3 rgrid((rows + 15) / 16);
+  hipLaunchKernelGGL((lora_dt_mfma_kernel<NSEG>), rgrid, dim3(256), 0, st, dy, B, dt, rows, segw, r, seg_mask, scale);
+  CLIPFS_CHECK(launch_status());
+  float* part_b = work;
+  hipLaunchKernelGGL(lora_db_mfma_kernel, dim3((cols + 255) / 256, slices_b), dim3(256), 0, st, dy, t, part_b, rows, cols,
+                     segw, NSEG, r, sr_b);
+  CLIPFS_CHECK(launch_status());
+  const size_t nb = (size_t)cols * r;
+  reduce(part_b, dB, nb, slices_b, scale, st);
+  CLIPFS_CHECK(launch_status());
+  float* part_a = work + (((size_t)slices_b * nb + 3) & ~(size_t)3);
+  hipLaunchKernelGGL((lora_da_mfma_kernel<NSEG>), dim3((width + 255) / 256, slices_a), dim3(256), 0, st, x, dt, part_a, rows,
+                     width, r, seg_mask, p, seed, stream_base, sr_a);
+  CLIPFS_CHECK(launch_status());
+  const size_t na = (size_t)NSEG * r * width;
+  reduce(part_a, dA, na, slices_a, 1.0f, st);
+  CLIPFS_CHECK(launch_status());
+  if (dx) {
+    switch ((r + 3) / 4) {
+      case 1:
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 1>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        break;
+      case 2:
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 2>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        break;
+      case 3:
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 3>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        break;
+      default:
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 4>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        break;
+    }
+    CLIPFS_CHECK(launch_status());
+  }
+  return CLIPFS_OK;
+}
+
+int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
+                  float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
+                  float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st,
+                  void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
+  if (nseg == 1)
+    return lora_bwd_mfma_n<1>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
+                              work, st, reduce);
+  return lora_bwd_mfma_n<3>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
+                            work, st, reduce);
+}
+
+}  // namespace clipfs

@@ -65,19 +65,19 @@ if __name__ == "__main__" and len(sys.argv) == 1:
 
 
 def lora_bench():
-    from clipfs import _lib
-    for M, d in ((12800, 768), (31031, 512)):
+    for M, d, r in ((12800, 768, 4), (31031, 512, 4), (32896, 1024, 16), (31031, 768, 16)):
         x = torch.randn(M, d, device=dev)
         dy = torch.randn(M, 3 * d, device=dev)
-        A = torch.randn(12, d, device=dev)
-        B = torch.randn(3 * d, 4, device=dev)
-        t = ops.lora_down(x, A, 4, 3)
+        A = torch.randn(3 * r, d, device=dev)
+        B = torch.randn(3 * d, r, device=dev)
+        t = ops.lora_down(x, A, r, 3)
         dA = torch.zeros_like(A)
         dB = torch.zeros_like(B)
         dx = torch.zeros_like(x)
         for p in (0.0, 0.25):
+            td = timeit(lambda: ops.lora_down(x, A, r, 3, p=p, seed=5 if p else 0))
             tm = timeit(lambda: ops.lora_bwd(dy, x, t, A, B, dA, dB, dx=dx, scale=0.5, p=p, seed=5 if p else 0))
-            print(f"lora_bwd M={M} d={d} p={p}: {tm*1e6:.1f} us")
+            print(f"lora M={M} d={d} r={r} p={p}: down {td*1e6:7.1f} us  bwd {tm*1e6:7.1f} us", flush=True)
 
 
 if __name__ == "__main__" and "--lora" in sys.argv:

@@ -151,10 +151,12 @@ def test_attention(dev, B, L, H, causal):
 
 # ------------------------------------------------------------------ LoRA
 @pytest.mark.parametrize("p", [0.0, 0.25])
-def test_lora_down_and_bwd(dev, p):
+@pytest.mark.parametrize("rows,width,r,nseg", [(333, 128, 4, 3), (200, 256, 16, 3), (77, 128, 16, 1), (150, 192, 2, 3),
+                                                (1100, 128, 8, 3), (90, 384, 1, 1)])
+def test_lora_down_and_bwd(dev, p, rows, width, r, nseg):
+    """width % 128 == 0 runs the fp32-MFMA kernels (lora_mfma.hip), 192 the one-wave-per-row kernels (lora.hip)."""
     from clipfs import ops
     from oracle import clip_oracle as O
-    rows, width, r, nseg = 333, 128, 4, 3
     seed, sb = 0x1234ABCD5, 7
     x = _rand(rows, width, seed=1)
     A = _rand(nseg * r, width, seed=2, scale=width ** -0.5).requires_grad_()
