@@ -134,13 +134,14 @@ int clipfs_attention_fwd(const float* qkv, float* out, float* lse, int batch, in
 int clipfs_attention_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv,
                          float* work, int batch, int seq, int heads, int causal, void* stream);
 size_t clipfs_attention_lse_floats(int batch, int seq, int heads);
-/* fp16 storage mode (cfg-5), non-causal, seq <= 288: the same function with both contractions on
+/* fp16 storage mode (cfg-5), seq <= 288: the same function with both contractions on
  * v_mfma_f32_32x32x16_f16 (operands rounded to f16 in the staging path; softmax statistics, accumulators and
  * outputs fp32).  lse as above (may be NULL when no backward follows). */
-int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, void* stream);
+int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal,
+                             void* stream);
 /* dqkv from (qkv, dout, out, lse) of clipfs_attention_f16_fwd; work: batch*heads*seq floats (D_i = dO_i . O_i). */
 int clipfs_attention_f16_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv,
-                             float* work, int batch, int seq, int heads, void* stream);
+                             float* work, int batch, int seq, int heads, int causal, void* stream);
 
 /* ------------------------------------------------------------------ LoRA --
  * t[m, s*r + j] = sum_k drop_s(x)[m,k] * A[s*r + j, k]       (the "down" half of

@@ -1,4 +1,4 @@
-// MFMA attention for the fp16 storage mode (cfg-5: ViT-L/14, L = 257, head_dim 64, non-causal): the same function
+// MFMA attention for the fp16 storage mode (cfg-5: ViT-L/14 image tower L = 257, text tower L = 77 causal; head_dim 64): the same function
 // as attention.hip (jclip/mha.py:55-83,439-458) with the two contractions on v_mfma_f32_32x32x16_f16, softmax
 // statistics and every accumulator in fp32.
 //
@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int AF_HD = 64;
 constexpr int AF_MAXL = 288;        // 9 tiles of 32 tokens
 constexpr int AF_ROW = 72;          // row-major image: halves per token row (64 + 8 pad: conflict-free ds_read_b128)
-constexpr int AF_TP = 292;          // transposed image: halves per feature row (conflict-free ds_read_b64)
+// transposed image: halves per feature row = Lp + 4 (= 4 * odd for Lp % 32 == 0: conflict-free ds_read_b64)
 constexpr float AF_LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ f16x8 cvt8(const f32x4& a, const f32x4& b) {
@@ -43,6 +43,7 @@ __device__ __forceinline__ f16x8 cvt8(const f32x4& a, const f32x4& b) {
 // image; tokens [L, Lp) are zero-filled so masked lanes multiply finite values.
 __device__ __forceinline__ void stage_head(const float* __restrict__ src, size_t ld, int L, int Lp, _Float16* rowm,
                                            _Float16* tr) {
+  const int TP = Lp + 4;
   if (rowm)  // feature chunk fastest: coalesced global reads, one ds_write_b128 per (token, chunk)
     for (int idx = threadIdx.x; idx < Lp * 8; idx += (int)blockDim.x) {
       const int tok = idx >> 3, c = idx & 7;
@@ -66,7 +67,7 @@ __device__ __forceinline__ void stage_head(const float* __restrict__ src, size_t
         h = cvt8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) tr[(8 * c + j) * AF_TP + tok] = h[j];
+      for (int j = 0; j < 8; ++j) tr[(8 * c + j) * TP + tok] = h[j];
     }
 }
 
@@ -92,8 +93,8 @@ __device__ __forceinline__ f32x16 scores_T(const _Float16* rowm, int t0, int lan
 
 // A operand of the token-axis contraction for key slice u (16 tokens) of the tile at t0: feature row (dt*32 + lane&31),
 // tokens t0 + 16 u + 4 fh + {0..3} and + 8 + {0..3}  (the tokens registers 8u .. 8u+7 of the lane hold).
-__device__ __forceinline__ f16x8 load_T(const _Float16* tr, int dt, int t0, int u, int lane) {
-  const _Float16* p = tr + (dt * 32 + (lane & 31)) * AF_TP + t0 + 16 * u + 4 * (lane >> 5);
+__device__ __forceinline__ f16x8 load_T(const _Float16* tr, int TP, int dt, int t0, int u, int lane) {
+  const _Float16* p = tr + (dt * 32 + (lane & 31)) * TP + t0 + 16 * u + 4 * (lane >> 5);
   const f16x4 lo = *reinterpret_cast<const f16x4*>(p);
   const f16x4 hi = *reinterpret_cast<const f16x4*>(p + 8);
   f16x8 v;
@@ -111,11 +112,11 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // forward
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                float* __restrict__ lse, int L, int H) {
+                                                                float* __restrict__ lse, int L, int H, int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int Lp = (L + 31) & ~31;
+  const int Lp = (L + 31) & ~31, TP = Lp + 4;
   _Float16* sK = reinterpret_cast<_Float16*>(smem_raw);  // [Lp][AF_ROW]
-  _Float16* sVt = sK + Lp * AF_ROW;                       // [64][AF_TP]
+  _Float16* sVt = sK + Lp * AF_ROW;                       // [64][TP]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = (int)blockDim.x >> 6;
@@ -138,13 +139,15 @@ __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m = -INFINITY, l = 0.f;
-    for (int k0 = 0; k0 < L; k0 += 32) {
+    const int kend = causal ? min(L, qt * 32 + 32) : L;  // causal: key tiles up to the diagonal tile
+    const int klim = causal ? q_tok : L - 1;             // last visible key of this lane's query
+    for (int k0 = 0; k0 < kend; k0 += 32) {
       f32x16 s = scores_T(sK, k0, lane, qf);
       float mt = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        s[r] = key < L ? s[r] * c : -INFINITY;
+        s[r] = (key < L && key <= klim) ? s[r] * c : -INFINITY;
         mt = fmaxf(mt, s[r]);
       }
       mt = fmaxf(mt, xor32(mt));
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __r
         for (int r = 0; r < 16; ++r) o[t][r] *= f;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sVt, t, k0, u, lane), pf[u], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sVt, TP, t, k0, u, lane), pf[u], o[t], 0, 0, 0);
       }
     }
     l += xor32(l);
@@ -195,9 +198,9 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* _
                                                                   const float* __restrict__ dout,
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ lse, float* __restrict__ dqkv,
-                                                                  float* __restrict__ Dbuf, int L, int H) {
+                                                                  float* __restrict__ Dbuf, int L, int H, int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int Lp = (L + 31) & ~31;
+  const int Lp = (L + 31) & ~31, TP = Lp + 4;
   _Float16* sK = reinterpret_cast<_Float16*>(smem_raw);
   _Float16* sV = sK + Lp * AF_ROW;
   _Float16* sKt = sV + Lp * AF_ROW;
@@ -238,21 +241,23 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* _
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int k0 = 0; k0 < L; k0 += 32) {
+    const int kend = causal ? min(L, qt * 32 + 32) : L;
+    const int klim = causal ? q_tok : L - 1;
+    for (int k0 = 0; k0 < kend; k0 += 32) {
       const f32x16 s = scores_T(sK, k0, lane, qf);
       const f32x16 dp = scores_T(sV, k0, lane, gf);
       f16x8 dsf[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const float p = key < L ? __builtin_amdgcn_exp2f(s[r] * c - lse2) : 0.f;
+        const float p = (key < L && key <= klim) ? __builtin_amdgcn_exp2f(s[r] * c - lse2) : 0.f;
         dsf[r >> 3][r & 7] = (_Float16)(p * (dp[r] - Di) * 0.125f);
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sKt, t, k0, u, lane), dsf[u], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sKt, TP, t, k0, u, lane), dsf[u], acc[t], 0, 0, 0);
     }
     if (q_tok < L) {
       float* op = dqkv + ((size_t)b * L + q_tok) * ld + h * AF_HD + 4 * fh;
@@ -278,14 +283,14 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
                                                                    const float* __restrict__ dout,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ Dbuf,
-                                                                   float* __restrict__ dqkv, int L, int H) {
+                                                                   float* __restrict__ dqkv, int L, int H, int causal) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int Lp = (L + 31) & ~31;
+  const int Lp = (L + 31) & ~31, TP = Lp + 4;
   _Float16* sQ = reinterpret_cast<_Float16*>(smem_raw);
   _Float16* sG = sQ + Lp * AF_ROW;
   _Float16* sQt = sG + Lp * AF_ROW;
-  _Float16* sGt = sQt + 64 * AF_TP;
-  float* sLse = reinterpret_cast<float*>(sGt + 64 * AF_TP);  // [Lp] in log2 units
+  _Float16* sGt = sQt + 64 * TP;
+  float* sLse = reinterpret_cast<float*>(sGt + 64 * TP);  // [Lp] in log2 units
   float* sD = sLse + Lp;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
         av[t][r] = 0.f;
         ak[t][r] = 0.f;
       }
-    for (int i0 = 0; i0 < L; i0 += 32) {
+    for (int i0 = causal ? kt * 32 : 0; i0 < L; i0 += 32) {  // causal: query tiles from the diagonal tile on
       const f32x16 s = scores_T(sQ, i0, lane, kf);
       const f32x16 dp = scores_T(sG, i0, lane, vf);
       f16x8 pf[2], dsf[2];
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g4 + j;
           const int qi = i0 + 8 * g4 + 4 * fh + j;
-          const float p = qi < L ? __builtin_amdgcn_exp2f(s[r] * c - l4[j]) : 0.f;
+          const float p = (qi < L && (!causal || qi >= k_tok)) ? __builtin_amdgcn_exp2f(s[r] * c - l4[j]) : 0.f;
           pf[r >> 3][r & 7] = (_Float16)p;
           dsf[r >> 3][r & 7] = (_Float16)(p * (dp[r] - d4[j]) * 0.125f);
         }
@@ -337,8 +342,8 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          av[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sGt, t, i0, u, lane), pf[u], av[t], 0, 0, 0);
-          ak[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sQt, t, i0, u, lane), dsf[u], ak[t], 0, 0, 0);
+          av[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sGt, TP, t, i0, u, lane), pf[u], av[t], 0, 0, 0);
+          ak[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(load_T(sQt, TP, t, i0, u, lane), dsf[u], ak[t], 0, 0, 0);
         }
     }
     if (k_tok < L) {
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
 
 static size_t af_lds_bytes(int L, int images_rowmajor, int images_transposed) {
   const int Lp = (L + 31) & ~31;
-  return ((size_t)images_rowmajor * Lp * AF_ROW + (size_t)images_transposed * 64 * AF_TP) * sizeof(_Float16);
+  return ((size_t)images_rowmajor * Lp * AF_ROW + (size_t)images_transposed * 64 * (Lp + 4)) * sizeof(_Float16);
 }
 
 }  // namespace clipfs
@@ -376,8 +381,13 @@ static int check_af(const void* a, const void* b, int batch, int seq, int heads)
   return CLIPFS_OK;
 }
 
+static int af_threads(int seq, int max_waves) {
+  const int tiles = (seq + 31) / 32;
+  return 64 * (tiles < max_waves ? tiles : max_waves);
+}
+
 extern "C" int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads,
-                                        void* stream) {
+                                        int causal, void* stream) {
   CLIPFS_CHECK(check_af(qkv, out, batch, seq, heads));
   static bool attr = false;
   if (!attr) {
@@ -385,13 +395,14 @@ extern "C" int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(attention_f16_fwd_kernel, dim3(batch * heads), dim3(320), af_lds_bytes(seq, 1, 1),
-                     (hipStream_t)stream, qkv, out, lse, seq, heads);
+  hipLaunchKernelGGL(attention_f16_fwd_kernel, dim3(batch * heads), dim3(af_threads(seq, 5)), af_lds_bytes(seq, 1, 1),
+                     (hipStream_t)stream, qkv, out, lse, seq, heads, causal);
   return launch_status();
 }
 
 extern "C" int clipfs_attention_f16_bwd(const float* qkv, const float* dout, const float* out, const float* lse,
-                                        float* dqkv, float* work, int batch, int seq, int heads, void* stream) {
+                                        float* dqkv, float* work, int batch, int seq, int heads, int causal,
+                                        void* stream) {
   CLIPFS_CHECK(check_af(qkv, dqkv, batch, seq, heads));
   CLIPFS_REQUIRE(dout && out && lse && work, "attention_f16_bwd: null pointer");
   static bool attr = false;
@@ -402,14 +413,13 @@ extern "C" int clipfs_attention_f16_bwd(const float* qkv, const float* dout, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  const int tiles = (seq + 31) / 32;
-  const int threads = 64 * (tiles < 9 ? tiles : 9);
+  const int threads = af_threads(seq, 9);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attention_f16_bwd_q_kernel, dim3(batch * heads), dim3(threads), af_lds_bytes(seq, 2, 1), st, qkv,
-                     dout, out, lse, dqkv, work, seq, heads);
+                     dout, out, lse, dqkv, work, seq, heads, causal);
   CLIPFS_CHECK(launch_status());
   const size_t lds_kv = af_lds_bytes(seq, 2, 2) + 2 * (size_t)((seq + 31) & ~31) * sizeof(float);
   hipLaunchKernelGGL(attention_f16_bwd_kv_kernel, dim3(batch * heads), dim3(threads), lds_kv, st, qkv, dout, lse, work,
-                     dqkv, seq, heads);
+                     dqkv, seq, heads, causal);
   return launch_status();
 }

@@ -26,7 +26,9 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
   L.t_qkv = o; o += al4(M * 3 * r);
   L.qkv = o;   o += al4(M * 3 * d);
   L.att = o;   o += al4(M * d);
-  L.lse = o;   o += al4(clipfs_attention_lse_floats((int)(M / t->seq), t->seq, t->heads));  // 0 for seq <= 96
+  // log-sum-exp rows: the long-sequence fp32 kernels (0 floats for seq <= 96) and every f16 MFMA attention need them
+  L.lse = o;   o += al4(t->weight_format == 2 ? (M / t->seq) * t->seq * (size_t)t->heads
+                                              : clipfs_attention_lse_floats((int)(M / t->seq), t->seq, t->heads));
   L.t_o = o;   o += al4(M * r);
   L.x_mid = o; o += al4(M * d);
   L.stat2 = o; o += al4(2 * M);
@@ -78,10 +80,8 @@ static int check_tower(const clipfs_tower* t, int batch) {
   return CLIPFS_OK;
 }
 
-// fp16 storage mode runs the medium-sequence, non-causal attention (ViT-L/14: 257 tokens) on the f16 MFMA kernels
-static inline bool f16_attention(const clipfs_tower* t) {
-  return t->weight_format == 2 && !t->causal && t->seq > 96 && t->seq <= 288;
-}
+// fp16 storage mode runs attention on the f16 MFMA kernels (attention_f16.hip; sequences up to 288 tokens)
+static inline bool f16_attention(const clipfs_tower* t) { return t->weight_format == 2 && t->seq <= 288; }
 
 static thread_local float* g_ws = nullptr;  // split-K scratch of the tower call in progress (its scratch buffer)
 static thread_local size_t g_ws_floats = 0;
@@ -175,7 +175,7 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
     CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
                       b.lora_b_qkv, r, 3, d, t->lora_scale, st));
     if (f16_attention(t))
-      CLIPFS_CHECK(clipfs_attention_f16_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, st));
+      CLIPFS_CHECK(clipfs_attention_f16_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
     else
       CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
     if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, st));
@@ -239,7 +239,8 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     }
     // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
     if (f16_attention(t))
-      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads, st));
+      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
+                                            t->causal, st));
     else
       CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
                                         t->causal, st));

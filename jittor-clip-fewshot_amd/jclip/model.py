@@ -153,7 +153,10 @@ class CLIP(nn.Module):
         return self.visual.conv1.weight.device
 
     def invalidate_engine(self):
-        """Called when the module tree changes (apply_lora) so pointers are re-collected."""
+        """Called when the module tree changes (apply_lora, FlatTrainables) so pointers are re-collected.  The
+        engine's user-visible settings (precision mode, text trimming) carry over to the rebuilt engine."""
+        if self._engine is not None:
+            self._engine_opts = (self._engine.precision, self._engine.trim_text)
         self._engine = None
 
     @property
@@ -161,6 +164,9 @@ class CLIP(nn.Module):
         if self._engine is None:
             from clipfs.engine import Engine
             self._engine = Engine(self)
+            opts = getattr(self, "_engine_opts", None)
+            if opts is not None:
+                self._engine.precision, self._engine.trim_text = opts
         return self._engine
 
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:

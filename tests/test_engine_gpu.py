@@ -455,11 +455,22 @@ def test_fp16_precision_mode_l14(dev, monkeypatch):
     with torch.no_grad():
         _, wl = O.train_step_loss(sd64, img.double(), cap, tgt, tl, vl, 0.25, text_chunk=Cn)
     model.eval()
-    model.engine.precision = "fp16"
     tr = L.LoRATrainer(model)
-    tr.flat.zero_grad()
-    _, _, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
-    e = _err(logits, wl)
-    assert 1e-5 < e < 5e-2, e
-    assert torch.equal(logits.argmax(1).cpu(), wl.argmax(1))
-    assert torch.isfinite(tr.flat.grads).all() and tr.flat.grads.abs().max() > 0
+    grads = {}
+    for mode in ("fp32", "fp16"):
+        model.engine.precision = mode
+        assert model.engine.precision == mode
+        tr.flat.zero_grad()
+        _, _, logits = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+        grads[mode] = tr.flat.grads.clone()
+        e = _err(logits, wl)
+        if mode == "fp32":
+            assert e < 1e-4, e
+        else:  # the f16 kernels really ran (error above fp32's) and stay inside fp16's budget
+            assert 1e-4 < e < 5e-2, e
+        assert torch.equal(logits.argmax(1).cpu(), wl.argmax(1))
+    g32, g16 = grads["fp32"], grads["fp16"]
+    assert torch.isfinite(g16).all() and g16.abs().max() > 0
+    # LoRA / prompt gradients of the fp16 path (f16 GEMM operands, f16 MFMA attention fwd + bwd) against the exact
+    # fp32 path: 3e-2 of the largest entry
+    assert (g16 - g32).abs().max().item() < 3e-2 * g32.abs().max().item()

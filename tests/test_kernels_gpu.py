@@ -439,34 +439,39 @@ def test_gemm_f16_operands(M, N, K, lora_r, act):
         assert (aux_out - pre).abs().max().item() <= 2e-5 * pre.abs().max().item() + 1e-5
 
 
-def _attn_ref64(qkv, batch, seq, heads):
+def _attn_ref64(qkv, batch, seq, heads, causal=False):
     d = heads * 64
     x = qkv.double().view(batch, seq, 3, heads, 64)
     q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
     s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((seq, seq), float("-inf"), dtype=torch.float64, device=s.device).triu(1)
     lse = torch.logsumexp(s, -1)
     o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(batch * seq, d)
     return o, lse.reshape(-1)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch,seq,heads", [(2, 257, 2), (1, 64, 1), (3, 50, 2), (1, 288, 1), (2, 33, 3)])
-def test_attention_f16_fwd(batch, seq, heads):
+@pytest.mark.parametrize("batch,seq,heads,causal", [(2, 257, 2, False), (1, 64, 1, False), (3, 50, 2, False),
+                                                     (1, 288, 1, False), (2, 33, 3, True), (3, 77, 2, True),
+                                                     (1, 130, 1, True)])
+def test_attention_f16_fwd(batch, seq, heads, causal):
     """fp16-mode MFMA attention forward vs an fp64 reference on the SAME f16-rounded q, k, v: what remains is the f16
     rounding of the probabilities (2^-11 relative per term) and fp32 accumulation: 2e-3 absolute on outputs of
     unit scale, 1e-3 on the log-sum-exp."""
     from clipfs import ops
     g = torch.Generator().manual_seed(seq)
     qkv = torch.randn(batch * seq, 3 * heads * 64, generator=g).half().float().cuda()
-    out, lse = ops.attention_f16_fwd(qkv, batch, seq, heads)
-    ro, rl = _attn_ref64(qkv, batch, seq, heads)
+    out, lse = ops.attention_f16_fwd(qkv, batch, seq, heads, causal)
+    ro, rl = _attn_ref64(qkv, batch, seq, heads, causal)
     assert (out.double() - ro).abs().max().item() < 2e-3
     assert (lse.double() - rl).abs().max().item() < 1e-3
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch,seq,heads", [(2, 257, 2), (1, 64, 1), (2, 50, 2), (1, 288, 1), (1, 100, 2)])
-def test_attention_f16_bwd(batch, seq, heads):
+@pytest.mark.parametrize("batch,seq,heads,causal", [(2, 257, 2, False), (1, 64, 1, False), (2, 50, 2, False),
+                                                     (1, 288, 1, False), (1, 100, 2, True), (3, 77, 2, True)])
+def test_attention_f16_bwd(batch, seq, heads, causal):
     """fp16-mode MFMA attention backward vs fp64 autograd on the same f16-rounded inputs.  P, dS and the staged
     operands are rounded to f16 (2^-11 relative each), accumulation is fp32: 1e-2 relative to the largest gradient
     entry, stated here (the exact-fp32 kernels are held to 1e-5 in test_attention)."""
@@ -474,10 +479,10 @@ def test_attention_f16_bwd(batch, seq, heads):
     g = torch.Generator().manual_seed(seq + 7)
     qkv = torch.randn(batch * seq, 3 * heads * 64, generator=g).half().float().cuda()
     dout = torch.randn(batch * seq, heads * 64, generator=g).half().float().cuda()
-    out, lse = ops.attention_f16_fwd(qkv, batch, seq, heads)
-    dqkv = ops.attention_f16_bwd(qkv, dout, out, lse, batch, seq, heads)
+    out, lse = ops.attention_f16_fwd(qkv, batch, seq, heads, causal)
+    dqkv = ops.attention_f16_bwd(qkv, dout, out, lse, batch, seq, heads, causal)
     x = qkv.double().requires_grad_(True)
-    ro, _ = _attn_ref64(x, batch, seq, heads)
+    ro, _ = _attn_ref64(x, batch, seq, heads, causal)
     (ro * dout.double()).sum().backward()
     ref = x.grad
     assert (dqkv.double() - ref).abs().max().item() < 1e-2 * ref.abs().max().item()
