@@ -127,10 +127,12 @@ int clipfs_layernorm_bwd(const float* dy, const float* x, int ldx, const float* 
 int clipfs_attention_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal,
                          void* stream);
 /* dqkv from dout, recomputing the probabilities from qkv.
- * seq <= 96: register/LDS-resident kernels; out, lse and work may be NULL.
- * seq  > 96 (ViT-L/14: 257): streaming kernels with an online softmax; the forward must have been given
- * lse [clipfs_attention_lse_floats] (log-sum-exp of the scaled scores per (batch, head, query)), the backward
- * needs the forward's `out`, that `lse` and a `work` buffer of the same size. */
+ * Default path, seq <= 288: exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32, scores kept transposed so that the
+ * softmax statistics are per-lane scalars).  The forward writes lse [clipfs_attention_lse_floats] (log-sum-exp of
+ * the scaled scores per (batch, head, query)) when given the buffer; the backward takes the forward's `out`, that
+ * `lse` and a `work` buffer of the same size.
+ * Without lse: seq <= 96 falls back to register/LDS-resident VALU kernels that recompute the softmax (out, lse and
+ * work may be NULL); seq > 96 requires lse; seq > 288 runs streaming kernels with an online softmax. */
 int clipfs_attention_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv,
                          float* work, int batch, int seq, int heads, int causal, void* stream);
 size_t clipfs_attention_lse_floats(int batch, int seq, int heads);

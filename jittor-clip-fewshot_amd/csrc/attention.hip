@@ -645,6 +645,14 @@ __global__ __launch_bounds__(512) void attention_lds_bwd_kv_kernel(const float* 
   }
 }
 
+// attention_mfma.hip: exact-fp32 MFMA kernels for seq <= 288 (the default path; the VALU kernels below remain for
+// longer sequences, for backward calls without the forward's lse, and as the CLIPFS_ATTN_MFMA=0 comparison)
+bool attention_mfma_enabled();
+int attention_mfma_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal, hipStream_t st);
+int attention_mfma_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv, float* work,
+                       int batch, int seq, int heads, int causal, hipStream_t st);
+constexpr int ATTN_MFMA_MAX = 288;
+
 static int check_attn(const char* what, int batch, int seq, int heads, int max_seq) {
   CLIPFS_REQUIRE(batch > 0 && heads > 0 && seq > 0 && seq <= max_seq, "%s: batch %d seq %d heads %d unsupported (seq <= %d)",
                  what, batch, seq, heads, max_seq);
@@ -672,6 +680,8 @@ extern "C" int clipfs_attention_fwd(const float* qkv, float* out, float* lse, in
   CLIPFS_CHECK(check_attn("attention_fwd", batch, seq, heads, ATTN_MAX_SEQ));
   CLIPFS_REQUIRE(qkv && out && aligned16(qkv), "attention_fwd: null or misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (attention_mfma_enabled() && seq <= ATTN_MFMA_MAX && aligned16(out))
+    return attention_mfma_fwd(qkv, out, lse, batch, seq, heads, causal, st);
   if ((seq > 128 || (seq > ATTN_FAST_MAX && lse)) && seq <= ATTN_LDS_MAX) {
     const size_t lds = ((size_t)2 * seq * KSTRIDE + 8 * 64) * sizeof(float);
     static bool attr = false;
@@ -708,6 +718,8 @@ extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, const f
   CLIPFS_CHECK(check_attn("attention_bwd", batch, seq, heads, ATTN_MAX_SEQ));
   CLIPFS_REQUIRE(qkv && dout && dqkv && aligned16(qkv) && aligned16(dout), "attention_bwd: null or misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (attention_mfma_enabled() && seq <= ATTN_MFMA_MAX && out && lse && work && aligned16(out) && aligned16(dqkv))
+    return attention_mfma_bwd(qkv, dout, out, lse, dqkv, work, batch, seq, heads, causal, st);
   if (seq > ATTN_FAST_MAX) {
     CLIPFS_REQUIRE(out && lse && work, "attention_bwd: seq %d > %d needs the forward's out and lse and a work buffer", seq,
                    ATTN_FAST_MAX);
@@ -763,5 +775,6 @@ extern "C" int clipfs_attention_bwd(const float* qkv, const float* dout, const f
 }
 
 extern "C" size_t clipfs_attention_lse_floats(int batch, int seq, int heads) {
+  if (attention_mfma_enabled() && seq <= ATTN_MFMA_MAX) return (size_t)batch * heads * seq;
   return seq > ATTN_FAST_MAX ? (size_t)batch * heads * seq : 0;
 }

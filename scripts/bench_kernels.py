@@ -45,13 +45,15 @@ def main():
     t = timeit(lambda: ops.attention_fwd(qkv, 256, 50, 12, False))
     print(f"attention fwd B=256 L=50 H=12: {t*1e6:.1f} us")
     do = torch.randn(12800, 768, device=dev)
-    t = timeit(lambda: ops.attention_bwd(qkv, do, 256, 50, 12, False))
+    o_, l_ = ops.attention_fwd(qkv, 256, 50, 12, False, want_lse=True)
+    t = timeit(lambda: ops.attention_bwd(qkv, do, 256, 50, 12, False, out=o_, lse=l_))
     print(f"attention bwd B=256 L=50 H=12: {t*1e6:.1f} us")
     qkv = torch.randn(31031, 1536, device=dev)
     t = timeit(lambda: ops.attention_fwd(qkv, 403, 77, 8, True))
     print(f"attention fwd B=403 L=77 H=8 causal: {t*1e6:.1f} us")
     do = torch.randn(31031, 512, device=dev)
-    t = timeit(lambda: ops.attention_bwd(qkv, do, 403, 77, 8, True))
+    o_, l_ = ops.attention_fwd(qkv, 403, 77, 8, True, want_lse=True)
+    t = timeit(lambda: ops.attention_bwd(qkv, do, 403, 77, 8, True, out=o_, lse=l_))
     print(f"attention bwd B=403 L=77 H=8 causal: {t*1e6:.1f} us")
     A = torch.randn(12, 768, device=dev)
     t = timeit(lambda: ops.lora_down(x, A, 4, 3))

@@ -139,14 +139,19 @@ def test_attention(dev, B, L, H, causal):
     mask = O.build_causal_mask(L, torch.float64) if causal else None
     o = O.sdpa(q, k, v, mask).permute(0, 2, 1, 3).reshape(B * L, d)
     qd = qkv.detach().float().to(dev)
-    got, lse = ops.attention_fwd(qd, B, L, H, causal, want_lse=True)  # lse is None on the short-sequence kernels
-    assert (lse is not None) == (L > 96)
+    got, lse = ops.attention_fwd(qd, B, L, H, causal, want_lse=True)  # fp32 MFMA kernels for L <= 288, streaming above
+    assert lse is not None
+    ref_lse = torch.logsumexp((q @ k.transpose(-1, -2)) * 0.125 + (mask if causal else 0), -1).reshape(-1)
+    _close(lse, ref_lse.detach(), 2e-5, "attention lse")
     _close(got, o, 2e-5, "attention fwd")
     _close(ops.attention_fwd(qd, B, L, H, causal), o, 2e-5, "attention fwd (inference)")
     do = _rand(B * L, d, seed=2)
     o.backward(do)
     dq = ops.attention_bwd(qd, do.float().to(dev), B, L, H, causal, out=got, lse=lse)
     _close(dq, qkv.grad, 5e-5, "attention bwd")
+    if L <= 96:  # without the forward's lse the backward falls back to the softmax-recomputing VALU kernels
+        dq2 = ops.attention_bwd(qd, do.float().to(dev), B, L, H, causal)
+        _close(dq2, qkv.grad, 5e-5, "attention bwd (no lse)")
 
 
 # ------------------------------------------------------------------ LoRA
