@@ -242,9 +242,18 @@ def main():
                 "bf16x3": ("gemm_bf16x3_kernel<.,.,2> (3 x v_mfma_f32_32x32x16_bf16 per operand pair)", 2500.0 / 3),
                 "fp16": ("gemm_f16_kernel<256,128> (v_mfma_f32_32x32x16_f16, both operands f16 via global_load_lds)", 2500.0),
             }[args.precision]
+            # HBM traffic per launch from the PMC counters cannot be collected from inside this process: it is the figure
+            # of the committed rocprofv3 --pmc passes over this same command (scripts/pmc_traffic.py), exact fp32 kernel only
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01", "gemm_traffic.json")
+            if args.precision == "fp32" and args.model == "b32" and os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
+                tsrc = "profiles/r01/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per the gfx950 note; L2-side counters: Infinity-Cache hits included)"
             roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": tsrc,
+                    "algorithmic_bytes_per_launch": round(lib.clipfs_gemm_timing_last_bytes() / n.value),
                     "launches_per_step": n.value, "avg_launch_us": round(tms.value * 1e3 / n.value, 2),
                     "gflop_per_launch": round(tfl.value / n.value / 1e9, 3),
                     "gemm_ms_per_step": round(tms.value, 3)}

@@ -105,6 +105,9 @@ size_t clipfs_gemm_workspace_floats(int M, int N, int K);
  * algorithmic FLOPs (2*M*N*K) and the number of launches since the last collect. */
 int clipfs_gemm_timing(int enable);
 int clipfs_gemm_timing_collect(double* total_ms, double* total_flops, int* launches);
+/* algorithmic HBM bytes (every operand, result and epilogue tensor counted once) of the launches summed by the last
+ * clipfs_gemm_timing_collect of the calling thread */
+double clipfs_gemm_timing_last_bytes(void);
 
 /* ------------------------------------------------------------- LayerNorm --
  * y = (x - mean) / sqrt(var + eps) * gamma + beta over the last dim (biased var).
@@ -218,6 +221,14 @@ int clipfs_logit_normalize(const float* z, float* out, float* work, int rows, in
 int clipfs_logit_normalize_bwd(const float* z, const float* dzn, float* dz, int rows, int classes, void* stream);
 /* out[c] = sum_r x[r,c] * (y ? y[r,c] : 1): bias / per-channel scale gradients of the head (fixed row order) */
 int clipfs_colsum(const float* x, const float* y, float* out, int rows, int cols, void* stream);
+/* Stage-2 self-consistency losses (slow_pace.py:1653-1658).
+ * l1_loss: loss[0] = mean |a - b| (jittor nn.l1_loss); da (may be NULL) = sign(a - b) * grad_scale / n.
+ * kl_logits: kl_div(log_softmax(logits), log_softmax(target_logits)) of slow_pace.py:1170-1177 per row:
+ *   loss_rows[r] = sum_j q_j (log q_j - log p_j); dlogits (may be NULL) = (p - q) * grad_scale; the caller sums the rows
+ *   and divides by numel (:1658). */
+int clipfs_l1_loss(const float* a, const float* b, size_t n, float* loss, float* da, float grad_scale, void* stream);
+int clipfs_kl_logits(const float* logits, const float* target_logits, float* loss_rows, float* dlogits, int rows,
+                     int classes, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------- optimiser --
  * jittor.optim.AdamW.step (lora_train_vlp.py:946,1002): p *= 1 - lr*wd; m,v update;

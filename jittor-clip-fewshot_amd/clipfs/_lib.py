@@ -73,6 +73,7 @@ SIGNATURES = {
     "clipfs_gemm_workspace_floats": (_sz, [_i, _i, _i]),
     "clipfs_gemm_timing": (_i, [_i]),
     "clipfs_gemm_timing_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "clipfs_gemm_timing_last_bytes": (C.c_double, []),
     "clipfs_layernorm_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "clipfs_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -99,6 +100,8 @@ SIGNATURES = {
     "clipfs_logit_normalize": (_i, [_p, _p, _p, _i, _i, _p]),
     "clipfs_logit_normalize_bwd": (_i, [_p, _p, _p, _i, _i, _p]),
     "clipfs_colsum": (_i, [_p, _p, _p, _i, _i, _p]),
+    "clipfs_l1_loss": (_i, [_p, _p, _sz, _p, _p, _f, _p]),
+    "clipfs_kl_logits": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "clipfs_adamw": (_i, [_p, _p, _p, _p, _sz, _i, _f, _f, _f, _f, _f, _f, _p]),
     "clipfs_mta_work_floats": (_sz, [_i, _i, _i, _i]),
     "clipfs_mta": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -343,3 +343,24 @@ def mta(feats, text, want_mode=True, want_logits=True):
     check(lib.clipfs_mta(_p(_f32(feats)), _p(_f32(text)), _p(mode), _p(logits), _p(work), n_img, V, d, Cn, _stream()),
           "mta")
     return mode, logits
+
+
+def l1_loss(a: torch.Tensor, b: torch.Tensor, want_grad: bool = False, grad_scale: float = 1.0):
+    """mean |a - b| (slow_pace.py:1654-1655); optionally d/da scaled by grad_scale."""
+    a, b = _f32(a).contiguous(), _f32(b).contiguous()
+    assert a.shape == b.shape
+    loss = torch.empty(1, device=a.device, dtype=torch.float32)
+    da = torch.empty_like(a) if want_grad else None
+    check(_lib.load().clipfs_l1_loss(_p(a), _p(b), a.numel(), _p(loss), _p(da), grad_scale, _stream()), "l1_loss")
+    return (loss, da) if want_grad else loss
+
+
+def kl_logits(logits: torch.Tensor, target_logits: torch.Tensor, want_grad: bool = False, grad_scale: float = 1.0):
+    """per-row KL(softmax(target) || softmax(logits)) (slow_pace.py:1656-1658 with kl_div :1170-1177)."""
+    x, t = _f32(logits).contiguous(), _f32(target_logits).contiguous()
+    assert x.shape == t.shape and x.dim() == 2
+    rows, cols = x.shape
+    loss_rows = torch.empty(rows, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x) if want_grad else None
+    check(_lib.load().clipfs_kl_logits(_p(x), _p(t), _p(loss_rows), _p(dx), rows, cols, grad_scale, _stream()), "kl_logits")
+    return (loss_rows, dx) if want_grad else loss_rows

@@ -450,6 +450,68 @@ static inline unsigned grid_for(size_t total) {
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+
+// ---- stage-2 self-consistency losses (slow_pace.py:1653-1658, kl_div :1170-1177) ----------------------------------
+// L1: loss = mean |a - b| ; da = sign(a - b) * grad_scale / n.  One 1024-thread block: fixed thread -> element
+// assignment and a fixed LDS tree, so the sum is bitwise reproducible (n is a few 1e5 on the path).
+__global__ __launch_bounds__(1024) void l1_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                       float* __restrict__ loss, float* __restrict__ da, float gscale) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float g = gscale / (float)n;
+  float acc = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const float d = a[i] - b[i];
+    acc += fabsf(d);
+    if (da) da[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    loss[0] = t / (float)n;
+  }
+}
+
+// KL(softmax(t) || softmax(x)) per row:  loss_rows[r] = sum_j q_j (log q_j - log p_j),  dx = (p - q) * grad_scale.
+// One wave per row (403 classes); both log-softmaxes with max subtraction.
+__global__ __launch_bounds__(256) void kl_logits_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                        float* __restrict__ loss_rows, float* __restrict__ dx, int rows,
+                                                        int cols, float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * cols;
+  const float* tr = t + (size_t)row * cols;
+  float mx = -INFINITY, mt = -INFINITY;
+  for (int j = lane; j < cols; j += 64) {
+    mx = fmaxf(mx, xr[j]);
+    mt = fmaxf(mt, tr[j]);
+  }
+  mx = wave_max(mx);
+  mt = wave_max(mt);
+  float sx = 0.f, st = 0.f;
+  for (int j = lane; j < cols; j += 64) {
+    sx += __expf(xr[j] - mx);
+    st += __expf(tr[j] - mt);
+  }
+  sx = wave_sum(sx);
+  st = wave_sum(st);
+  const float lx = mx + __logf(sx), lt = mt + __logf(st);
+  float acc = 0.f;
+  for (int j = lane; j < cols; j += 64) {
+    const float a = xr[j] - lx, b = tr[j] - lt;  // log p, log q
+    const float q = __expf(b);
+    acc += q * (b - a);
+    if (dx) dx[(size_t)row * cols + j] = (__expf(a) - q) * gscale;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) loss_rows[row] = acc;
+}
+
 }  // namespace clipfs
 
 using namespace clipfs;
@@ -577,5 +639,20 @@ extern "C" int clipfs_adamw(float* p, const float* g, float* m, float* v, size_t
   const double bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                      beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), (float)((double)lr / bc1), grad_scale);
+  return launch_status();
+}
+
+extern "C" int clipfs_l1_loss(const float* a, const float* b, size_t n, float* loss, float* da, float grad_scale,
+                              void* stream) {
+  CLIPFS_REQUIRE(a && b && loss && n > 0, "l1_loss: bad args");
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, loss, da, grad_scale);
+  return launch_status();
+}
+
+extern "C" int clipfs_kl_logits(const float* logits, const float* target_logits, float* loss_rows, float* dlogits,
+                                int rows, int classes, float grad_scale, void* stream) {
+  CLIPFS_REQUIRE(logits && target_logits && loss_rows && rows > 0 && classes > 0, "kl_logits: bad args");
+  hipLaunchKernelGGL(kl_logits_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, target_logits,
+                     loss_rows, dlogits, rows, classes, grad_scale);
   return launch_status();
 }

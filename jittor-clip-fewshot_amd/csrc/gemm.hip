@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(const GemmPara
 struct TimedLaunch {
   hipEvent_t start, stop;
   double flops;
+  double bytes;  // algorithmic HBM bytes: each operand, result and epilogue tensor touched once
 };
+static thread_local double g_last_bytes = 0.0;
 static thread_local bool g_timing = false;
 static thread_local std::vector<TimedLaunch>* g_timed = nullptr;
 
@@ -345,8 +347,10 @@ extern "C" int clipfs_gemm_timing(int enable) {
   return CLIPFS_OK;
 }
 
+extern "C" double clipfs_gemm_timing_last_bytes(void) { return g_last_bytes; }
+
 extern "C" int clipfs_gemm_timing_collect(double* total_ms, double* total_flops, int* launches) {
-  double ms = 0.0, fl = 0.0;
+  double ms = 0.0, fl = 0.0, by = 0.0;
   int n = 0;
   if (g_timed) {
     for (TimedLaunch& t : *g_timed) {
@@ -354,6 +358,7 @@ extern "C" int clipfs_gemm_timing_collect(double* total_ms, double* total_flops,
       if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&e, t.start, t.stop) == hipSuccess) {
         ms += e;
         fl += t.flops;
+        by += t.bytes;
         ++n;
       }
       (void)hipEventDestroy(t.start);
@@ -361,6 +366,7 @@ extern "C" int clipfs_gemm_timing_collect(double* total_ms, double* total_flops,
     }
     g_timed->clear();
   }
+  g_last_bytes = by;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = n;
@@ -380,6 +386,13 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
   (void)hipEventCreate(&tl.start);
   (void)hipEventCreate(&tl.stop);
   tl.flops = args ? 2.0 * args->M * (double)args->N * args->K : 0.0;
+  tl.bytes = 0.0;
+  if (args) {
+    const double mk = (double)args->M * args->K, nk = (double)args->N * args->K, mn = (double)args->M * args->N;
+    const double ab = args->A_f16 ? 2.0 : 4.0, bb = args->B_planes ? (args->b_format == 1 ? 4.0 : 2.0) : 4.0;
+    tl.bytes = ab * mk + bb * nk + (args->C ? 4.0 : 0.0) * mn + (args->C_f16 ? 2.0 : 0.0) * mn +
+               4.0 * mn * ((args->residual ? 1 : 0) + (args->aux_out && args->act == 1 ? 1 : 0) + (args->act == 2 ? 1 : 0));
+  }
   (void)hipEventRecord(tl.start, (hipStream_t)stream);
   const int rc = gemm_nt_impl(args, stream);
   (void)hipEventRecord(tl.stop, (hipStream_t)stream);
@@ -450,7 +463,7 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   static const int tile_cfg = getenv("CLIPFS_GEMM_TILE") ? atoi(getenv("CLIPFS_GEMM_TILE")) : 0;  // tuning aid
   if (tile_cfg == 1 && a.a_mode == 0 && (a.K % BK) == 0) {
     p.n_blocks_n = (a.N + 127) / 128;
-    return launch<128, 128, 0>(p, s);
+    return launch<128, 128, 3>(p, s);
   }
   if (tile_cfg == 2 && a.a_mode == 0 && (a.K % BK) == 0) {
     p.n_blocks_n = (a.N + 63) / 64;

@@ -6,7 +6,14 @@
     logit_normalize   slow_pace.py:1276-1280
     solve_mta         slow_pace.py:1363-1433 MTA returning the MODE feature [1, d]
 
-The stage-2 loss zoo (SCL / KL / MoCo, slow_pace.py:1479-1716) is out of scope.
+    l1_loss / kl_div  slow_pace.py:1653-1658,1170-1177  the SCL self-consistency terms
+    CosineAnnealingLR slow_pace.py:1591      jt.lr_scheduler.CosineAnnealingLR(total_epoch, eta_min=1e-6)
+    stage2_loss       slow_pace.py:1622-1688 the stage-2 objective without the MoCo branch
+    Stage2Trainer     slow_pace.py:1590-1697 the loop body (prompt ctx + VPT + head, AdamW + cosine LR)
+    load_lora_swa     slow_pace.py:736-816   average of several saved LoRA files
+
+The MoCo-v3 auxiliary branch (moco_model / Moco_Adapter, slow_pace.py:1677-1680) stays out of scope (SURVEY.md
+section 2 row 17): ``stage2_loss`` is ``sim_ce + L_SCL + lp_ce``, i.e. :1688 without ``loss_aux``.
 """
 from __future__ import annotations
 
@@ -155,6 +162,198 @@ class Channel_LP(nn.Module):
 def logit_normalize(logit: torch.Tensor) -> torch.Tensor:
     """slow_pace.py:1276-1280 (differentiable)."""
     return _LogitNormFn.apply(logit.float())
+
+
+def load_lora_swa(args, list_lora_layers, swa_weights_folder: str) -> int:
+    """slow_pace.py:736-816: element-wise average of every ``save_lora`` file in ``swa_weights_folder`` (sub-folders
+    skipped, any metadata mismatch -> ValueError, missing folder -> FileNotFoundError; the reference's metadata check
+    reads ``args.alpha_lora``, falling back here to ``args.alpha`` which the rest of the API uses), written into the
+    adapters.  Files are read with the inert pickle reader; the average is accumulated in float64 in directory-listing
+    order and rounded once.  Returns the number of files averaged."""
+    import os
+
+    import numpy as np
+
+    from clipfs import safe_pkl
+    from lora_train_vlp import _PROJ_NAME
+    if not os.path.exists(swa_weights_folder):
+        raise FileNotFoundError(f"folder {swa_weights_folder} does not exist.")
+    acc, count = None, 0
+    alpha = getattr(args, "alpha_lora", getattr(args, "alpha", None))
+    for filename in os.listdir(swa_weights_folder):
+        path = os.path.join(swa_weights_folder, filename)
+        if os.path.isdir(path):
+            continue
+        loaded = safe_pkl.load(path)
+        md = loaded["metadata"]
+        for key, want in (("r", args.r), ("alpha", alpha), ("encoder", args.encoder), ("position", args.position)):
+            if md[key] != want:
+                raise ValueError(f"{key} mismatch: expected {want}, found {md[key]}")
+        if list(md["params"]) != list(args.params):
+            raise ValueError(f"params mismatch: expected {args.params}, found {md['params']}")
+        weights = loaded["weights"]
+        if acc is None:
+            acc = {ln: {pn: {k: np.zeros(np.shape(v), np.float64) for k, v in ab.items()} for pn, ab in lw.items()}
+                   for ln, lw in weights.items()}
+        for ln, lw in weights.items():
+            for pn, ab in lw.items():
+                for k, v in ab.items():
+                    acc[ln][pn][k] += np.asarray(v, np.float64)
+        count += 1
+    if count == 0:
+        raise ValueError(f"no LoRA files in {swa_weights_folder}")
+    with torch.no_grad():
+        for i, layer in enumerate(list_lora_layers):
+            lw = acc[f"layer_{i}"]
+            for p in ("q", "k", "v", "o"):
+                name = _PROJ_NAME[p]
+                if p in args.params and name in lw:
+                    m = getattr(layer, name)
+                    m.w_lora_A.data.copy_(torch.from_numpy((lw[name]["w_lora_A"] / count).astype(np.float32)))
+                    m.w_lora_B.data.copy_(torch.from_numpy((lw[name]["w_lora_B"] / count).astype(np.float32)))
+    return count
+
+
+class _L1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        loss, da = ops.l1_loss(a, b, want_grad=True)
+        ctx.save_for_backward(da)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (da,) = ctx.saved_tensors
+        return da * g, None
+
+
+def l1_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """jittor ``nn.l1_loss``: mean |output - target| (slow_pace.py:1654-1655); gradient flows to ``output`` only (the
+    zero-shot side is a constant there)."""
+    return _L1Fn.apply(output.float(), target.detach().float())
+
+
+class _KLLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target_logits, denom):
+        rows, dx = ops.kl_logits(logits, target_logits, want_grad=True, grad_scale=1.0 / denom)
+        ctx.save_for_backward(dx)
+        return rows.sum() / denom
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g, None, None
+
+
+def scl_logits_loss(cosine_similarity: torch.Tensor, zero_shot_logits: torch.Tensor) -> torch.Tensor:
+    """slow_pace.py:1656-1658: ``kl_div(log_softmax(cos), log_softmax(zs), 'sum') / cos.numel()`` with ``kl_div`` of
+    :1170-1177 (= sum exp(b) (b - a)); the zero-shot logits carry no gradient (:1651 ``jt.no_grad``)."""
+    return _KLLogitsFn.apply(cosine_similarity.float(), zero_shot_logits.detach().float(), float(cosine_similarity.numel()))
+
+
+class CosineAnnealingLR:
+    """``jt.lr_scheduler.CosineAnnealingLR(optimizer, T_max, eta_min)`` as slow_pace.py:1591,1697 uses it: after
+    ``step()`` number ``t`` the learning rate is ``eta_min + (base_lr - eta_min) * (1 + cos(pi * t / T_max)) / 2``."""
+
+    def __init__(self, base_lr: float, T_max: int, eta_min: float = 1e-6):
+        self.base_lr, self.T_max, self.eta_min = float(base_lr), int(T_max), float(eta_min)
+        self.last_epoch = 0
+
+    def get_lr(self) -> float:
+        import math
+        return self.eta_min + (self.base_lr - self.eta_min) * (1.0 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2.0
+
+    def step(self) -> float:
+        self.last_epoch += 1
+        return self.get_lr()
+
+
+def stage2_loss(image_features: torch.Tensor, text_features: torch.Tensor, target: torch.Tensor,
+                zs_image_features: torch.Tensor, zs_text_features: torch.Tensor, channel_lp: "Channel_LP",
+                lp_image_features: torch.Tensor, lp_text_features: torch.Tensor):
+    """The stage-2 objective of slow_pace.py:1636-1688 without the MoCo term.
+
+    ``image_features`` [B, d] / ``text_features`` [C, d]: the prompted, UN-normalised tower outputs (with grad);
+    ``zs_*``: the cached zero-shot features (unit norm, constants; :1650,1654-1655);
+    ``lp_image_features`` [B, d]: raw image features of a second, no-grad forward (:1660-1661), ``lp_text_features``
+    [C, d]: one of the cached zero-shot template sets (:1662) -- the Channel_LP head is trained on their concatenation
+    with targets ``concat(target, arange(C))`` (:1663-1669).
+    Returns (loss, dict of the terms, cosine_similarity)."""
+    img = E.l2_normalize(image_features)
+    txt = E.l2_normalize(text_features)
+    cos = E.cosine_logits(img, txt, 100.0)                                   # :1640
+    with torch.no_grad():
+        zs_logits = E.cosine_logits(zs_image_features.float(), zs_text_features.float(), 100.0)  # :1650
+    loss_scl_text = l1_loss(txt, zs_text_features)                           # :1654
+    loss_scl_image = l1_loss(img, zs_image_features)                         # :1655
+    loss_scl_logits = scl_logits_loss(cos, zs_logits)                        # :1656-1658
+    feats = torch.cat((lp_image_features.detach().float(), lp_text_features.detach().float()), dim=0)  # :1663
+    out_lp = logit_normalize(channel_lp(feats))                              # :1665-1666
+    C = text_features.shape[0]
+    tgt_lp = torch.cat((target.to(out_lp.device).long(), torch.arange(C, device=out_lp.device)))  # :1667-1668
+    lp_ce = E.cross_entropy_loss(out_lp, tgt_lp)                             # :1669
+    sim_ce = E.cross_entropy_loss(cos, target)                               # :1686
+    l_scl = loss_scl_logits + loss_scl_text + loss_scl_image                 # :1684
+    loss = sim_ce + l_scl + lp_ce                                            # :1688 minus loss_aux
+    terms = {"sim_ce": sim_ce, "scl_text": loss_scl_text, "scl_image": loss_scl_image, "scl_logits": loss_scl_logits,
+             "lp_ce": lp_ce}
+    return loss, terms, cos
+
+
+class Stage2Trainer:
+    """The loop body of slow_pace.py:1622-1697 (MoCo branch excluded) as one object: prompt ctx + VPT tokens +
+    Channel_LP head are trained (the LoRA adapters stay applied but frozen: :1551-1556 clears ``requires_grad`` on
+    everything of the CLIP model that is not a VPT parameter), AdamW(weight_decay 1e-2, betas (0.9, 0.999)) with
+    ``CosineAnnealingLR(total_epoch, eta_min=1e-6)`` stepped once per iteration (:1590-1591,1696-1697).
+
+    ``zs_image_features`` [N, d]: cached unit-norm zero-shot image features of the training set (``features_zs1.pkl``
+    in the reference), indexed by the loader's sample index; ``zs_text_features`` [C, d]: zero-shot classifier;
+    ``zs_text_feature_sets``: the cached per-template-file classifiers one of which is drawn per step (:1603-1609,1662)."""
+
+    def __init__(self, clip_model, prompt_learner: "VLPromptLearner", channel_lp: "Channel_LP",
+                 zs_image_features: torch.Tensor, zs_text_features: torch.Tensor,
+                 zs_text_feature_sets: Optional[Sequence[torch.Tensor]] = None, lr: float = 2e-4, total_epoch: int = 20,
+                 weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.model, self.prompt_learner, self.head = clip_model, prompt_learner, channel_lp
+        self.text_encoder = TextEncoder(clip_model)
+        dev = clip_model.device
+        self.zs_img = zs_image_features.to(dev, torch.float32)
+        self.zs_txt = zs_text_features.to(dev, torch.float32)
+        self.zs_sets = [t.to(dev, torch.float32) for t in (zs_text_feature_sets or [zs_text_features])]
+        self.params: List[nn.Parameter] = [prompt_learner.ctx]
+        if clip_model.visual.VPT is not None:
+            clip_model.visual.VPT.requires_grad_(True)
+            self.params.append(clip_model.visual.VPT)
+        self.params += list(channel_lp.parameters())
+        self.m = [torch.zeros_like(p.data) for p in self.params]
+        self.v = [torch.zeros_like(p.data) for p in self.params]
+        self.sched = CosineAnnealingLR(lr, total_epoch)
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.t = 0
+
+    def loss(self, images: torch.Tensor, target: torch.Tensor, index: torch.Tensor, template_choice: int = 0):
+        m = self.model
+        text_features = self.text_encoder(self.prompt_learner())                  # :1626-1629
+        image_features = m.encode_image(images)                                   # :1636
+        with torch.no_grad():
+            lp_img = m.encode_image(images)                                       # :1660-1661 (second forward)
+        zs_img = self.zs_img[index.to(self.zs_img.device)]
+        return stage2_loss(image_features, text_features, target.to(m.device), zs_img, self.zs_txt, self.head, lp_img,
+                           self.zs_sets[template_choice % len(self.zs_sets)])
+
+    def step(self, images, target, index, template_choice: int = 0):
+        for p in self.params:
+            p.grad = None
+        loss, terms, cos = self.loss(images, target, index, template_choice)
+        loss.backward()
+        self.t += 1
+        for p, mm, vv in zip(self.params, self.m, self.v):
+            if p.grad is not None:
+                ops.adamw(p.data.view(-1), p.grad.contiguous().view(-1), mm.view(-1), vv.view(-1), self.t, self.lr,
+                          self.betas, self.eps, self.wd, 1.0)
+        self.lr = self.sched.step()                                               # :1697
+        return loss.detach(), terms, cos.detach()
 
 
 @torch.no_grad()

@@ -494,6 +494,66 @@ def logit_normalize(logit: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------
+# Stage-2 objective (slow_pace.py:1590-1697), MoCo branch excluded
+# --------------------------------------------------------------------------
+
+
+def jt_l1_loss(output: Tensor, target: Tensor) -> Tensor:
+    """jittor.nn.l1_loss: mean |output - target| (slow_pace.py:1654-1655)."""
+    return (output - target).abs().mean()
+
+
+def kl_div(log_probs: Tensor, target_log_probs: Tensor, reduction: str = "sum") -> Tensor:
+    """slow_pace.py:1170-1177 verbatim semantics: exp(target) * (target - log_probs)."""
+    kl = torch.exp(target_log_probs) * (target_log_probs - log_probs)
+    if reduction == "sum":
+        return kl.sum()
+    if reduction == "mean":
+        return kl.mean()
+    return kl
+
+
+def jt_log_softmax(x: Tensor, dim: int = 1) -> Tensor:
+    z = x - x.max(dim=dim, keepdim=True).values
+    return z - torch.log(torch.exp(z).sum(dim=dim, keepdim=True))
+
+
+def scl_logits_loss(cosine_similarity: Tensor, zero_shot_logits: Tensor) -> Tensor:
+    """slow_pace.py:1656-1658."""
+    a = jt_log_softmax(cosine_similarity / 1, 1)
+    b = jt_log_softmax(zero_shot_logits / 1, 1)
+    return kl_div(a, b, reduction="sum") * (1 * 1) / cosine_similarity.numel()
+
+
+def cosine_annealing_lr(base_lr: float, t: int, T_max: int, eta_min: float = 1e-6) -> float:
+    """jt.lr_scheduler.CosineAnnealingLR (slow_pace.py:1591): lr after t scheduler steps (closed form)."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * t / T_max)) / 2.0
+
+
+def stage2_loss(image_features: Tensor, text_features: Tensor, target: Tensor, zs_image_features: Tensor,
+                zs_text_features: Tensor, lp_params: Tuple[Tensor, Tensor, Tensor, Tensor], lp_image_features: Tensor,
+                lp_text_features: Tensor) -> Tuple[Tensor, Dict[str, Tensor], Tensor]:
+    """slow_pace.py:1636-1688 without loss_aux (MoCo): sim_ce + (L_SCL_logits + L1 text + L1 image) + lp_ce.
+    ``lp_params`` = (scale1, bias1, fc.weight, fc.bias) of Channel_LP."""
+    img = image_features / image_features.norm(dim=-1, keepdim=True)            # :1630
+    txt = text_features / text_features.norm(dim=-1, keepdim=True)              # :1631
+    cos = 100 * img @ txt.t()                                                   # :1640
+    zs_logits = 100 * zs_image_features @ zs_text_features.t()                  # :1650
+    scl_text = jt_l1_loss(txt, zs_text_features)                                # :1654
+    scl_image = jt_l1_loss(img, zs_image_features)                              # :1655
+    scl_logits = scl_logits_loss(cos, zs_logits)                                # :1656-1658
+    feats = torch.cat((lp_image_features, lp_text_features), dim=0)             # :1663
+    out_lp = logit_normalize(channel_lp(feats, *lp_params))                     # :1665-1666
+    C = text_features.shape[0]
+    tgt = torch.cat((target.long(), torch.arange(C)))                           # :1667-1668
+    lp_ce = jt_cross_entropy(out_lp, tgt)                                       # :1669
+    sim_ce = jt_cross_entropy(cos, target)                                      # :1686
+    loss = sim_ce + (scl_logits + scl_text + scl_image) + lp_ce                 # :1684,1688 (minus loss_aux)
+    return loss, {"sim_ce": sim_ce, "scl_text": scl_text, "scl_image": scl_image, "scl_logits": scl_logits,
+                  "lp_ce": lp_ce}, cos
+
+
+# --------------------------------------------------------------------------
 # MTA  (lora_train_vlp.py:733-811 ; slow_pace.py:1363-1433)
 # --------------------------------------------------------------------------
 
