@@ -20,9 +20,11 @@ constexpr int BK = 32;
 
 // The fused epilogue for one output element (order documented in include/clipfs.h); used by the GEMM
 // kernel and by the split-K combine kernel.
-__device__ __forceinline__ void epilogue_store(const clipfs_gemm_args& g, int patches, int m, int n, float accv) {
+// lora_done: the rank-r term is already inside accv (added on the matrix cores after the K loop; alpha == 1 there)
+__device__ __forceinline__ void epilogue_store(const clipfs_gemm_args& g, int patches, int m, int n, float accv,
+                                               bool lora_done = false) {
   float v = g.alpha * accv + (g.bias ? g.bias[n] : 0.f);
-  if (g.lora_t) {
+  if (g.lora_t && !lora_done) {
     const int lseg = n / g.lora_seg_width;
     const float* lb = g.lora_b + (size_t)n * g.lora_r;
     const float* t = g.lora_t + (size_t)m * (g.lora_nseg * g.lora_r) + lseg * g.lora_r;
