@@ -23,7 +23,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int AM_HD = 64;
-constexpr int AM_MAXL = 288;
 constexpr float AM_LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

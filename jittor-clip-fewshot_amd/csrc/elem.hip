@@ -357,7 +357,6 @@ __global__ __launch_bounds__(1024) void logit_normalize_bwd_kernel(const float* 
                                                                    const float* __restrict__ dzn, float* __restrict__ dz,
                                                                    int rows, int classes) {
   __shared__ float red[16];
-  __shared__ float stat[3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t n = (size_t)rows * classes;
   auto block_total = [&](float v) -> float {

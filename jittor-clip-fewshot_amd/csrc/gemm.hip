@@ -252,104 +252,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   compute(smem + ((nk - 1) & 1) * STAGE_FLOATS);
   }
 
-  // ---- rank-r LoRA up-projection on the matrix cores: ceil(r / 2) more K-steps of the 32x32x2 MFMA with
-  // A = lora_scale * t[m, seg r + k], B = lora_b[n, k] (a 32-column tile lies inside one segment: the host checks
-  // lora_seg_width % 32 == 0).  The per-element epilogue would cost 2 x 16-byte loads + r FMAs per output instead.
-  const bool lora_mfma = g.lora_t && p.splits == 1 && g.alpha == 1.f;
-  if (lora_mfma) {
-    const int r = g.lora_r, tw = g.lora_nseg * r;
-    const int rsteps = (r + 1) >> 1;
-    for (int st = 0; st < rsteps; ++st) {
-      const int k = 2 * st + fh;
-      const float kmask = k < r ? 1.f : 0.f;
-      const int kc2 = min(k, r - 1);
-      float bv[TN];
-      int segs[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * (BN / WN) + j * 32;
-        segs[j] = min(nb, N - 1) / g.lora_seg_width;
-        bv[j] = g.lora_b[(size_t)min(nb + fr, N - 1) * r + kc2] * kmask;
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = min(m0 + wm * (BM / WM) + i * 32 + fr, M - 1);
-        const float* tp = g.lora_t + (size_t)m * tw + kc2;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const float av = g.lora_scale * tp[segs[j] * r];
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  // ---- epilogue ------------------------------------------------------------------------------
-  // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  // Dense rows (a_mode 0), whole tile inside the problem, no split: every option is a wave-uniform branch around
-  // a 16-element pass with all of its loads issued together (the generic per-element path serialises them).
-  const bool fast = g.a_mode == 0 && p.splits == 1 && (lora_mfma || !g.lora_t) && m0 + BM <= M && n0 + BN <= N;
-  if (fast) {
-    const int ldc = g.ldc;
+  // ---- LoRA up-projection on the matrix cores + epilogue (gemm_common.h) ------------------------------------
+  if (p.splits > 1) {
+    // raw partial sums of this K slice; gemm_splitk_combine_kernel adds the slices in order and applies the epilogue
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / WN) + j * 32 + fr;
-      const float bias = g.bias ? g.bias[n] : 0.f;
+      if (n >= N) continue;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + wm * (BM / WM) + i * 32 + 4 * fh;
-        const size_t base = (size_t)mb * ldc + n;
-        float v[16];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
-        if (g.act == 1) {
-          if (g.aux_out) {
-            float* q = g.aux_out + base;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = quick_gelu(v[r]);
-        } else if (g.act == 2) {
-          const float* q = g.aux_in + base;
-          float u[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * ldc];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad(u[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (m < M) p.part[((size_t)split * M + m) * N + n] = acc[i][j][r];
         }
-        if (g.residual) {
-          const float* q = g.residual + (size_t)mb * g.ldres + n;
-          float u[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * g.ldres];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += u[r];
-        }
-        float* q = g.C + base;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
-      }
     }
     return;
   }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / WN) + j * 32 + fr;
-    if (n >= N) continue;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m >= M) continue;
-        if (p.splits > 1)
-          p.part[((size_t)split * M + m) * N + n] = acc[i][j][r];  // raw partial sum; combined in fixed order
-        else
-          epilogue_store(g, p.patches, m, n, acc[i][j][r], lora_mfma);
-      }
-    }
-  }
+  finish_tiles<TM, TN>(g, p.patches, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), m0 + BM <= M && n0 + BN <= N, lane);
 }
 
 // split-K combine: C = epilogue( sum_s part[s] ), slabs added in index order (bitwise reproducible)

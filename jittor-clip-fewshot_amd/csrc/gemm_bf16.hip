@@ -234,19 +234,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const Bf16Params bp) {
   }
   compute(smem_raw + ((nk - 1) & 1) * STAGE);
 
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / 2) + j * 32 + fr;
-    if (n >= N) continue;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (m < M) epilogue_store(g, p.patches, m, n, acc[i][j][r]);
-      }
-    }
-  }
+  finish_tiles<TM, TN>(g, p.patches, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), m0 + BM <= M && n0 + BN <= N, lane);
 }
 
 template <int BM, int BN, int NPL>

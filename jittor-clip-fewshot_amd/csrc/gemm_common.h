@@ -49,6 +49,108 @@ __device__ __forceinline__ void epilogue_store(const clipfs_gemm_args& g, int pa
 }
 
 
+// What every 32x32-MFMA GEMM kernel does after its K loop, for the TM x TN accumulator tiles of one wave whose
+// first row / column are mw / nw (C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) +
+// 4 (lane >> 5)):
+//  1. rank-r LoRA up-projection on the matrix cores: ceil(r / 2) more K-steps of v_mfma_f32_32x32x2_f32 with
+//     A = lora_scale * t[m, seg r + k], B = lora_b[n, k] (a 32-column tile lies inside one segment: the host checks
+//     lora_seg_width % 32 == 0) -- the per-element epilogue would cost 2 x 16-byte loads + r FMAs per output;
+//  2. the epilogue.  Dense rows and the whole block tile inside the problem (full_tile): every option is a
+//     wave-uniform branch around a 16-element pass with all of its loads issued together; otherwise the generic
+//     per-element path (ragged edges, patch row remap).
+template <int TM, int TN>
+__device__ __forceinline__ void finish_tiles(const clipfs_gemm_args& g, int patches, f32x16 (&acc)[TM][TN], int mw, int nw,
+                                             bool full_tile, int lane) {
+  const int fr = lane & 31, fh = lane >> 5;
+  const int M = g.M, N = g.N;
+  const bool lora_mfma = g.lora_t && g.alpha == 1.f;
+  if (lora_mfma) {
+    const int r = g.lora_r, tw = g.lora_nseg * r;
+    const int rsteps = (r + 1) >> 1;
+    for (int st = 0; st < rsteps; ++st) {
+      const int k = 2 * st + fh;
+      const float kmask = k < r ? 1.f : 0.f;
+      const int kc2 = min(k, r - 1);
+      float bv[TN];
+      int segs[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nb = nw + j * 32;
+        segs[j] = min(nb, N - 1) / g.lora_seg_width;
+        bv[j] = g.lora_b[(size_t)min(nb + fr, N - 1) * r + kc2] * kmask;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = min(mw + i * 32 + fr, M - 1);
+        const float* tp = g.lora_t + (size_t)m * tw + kc2;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float av = g.lora_scale * tp[segs[j] * r];
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (g.a_mode == 0 && full_tile && (lora_mfma || !g.lora_t)) {
+    const int ldc = g.ldc;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + j * 32 + fr;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = mw + i * 32 + 4 * fh;
+        const size_t base = (size_t)mb * ldc + n;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
+        if (g.act == 1) {
+          if (g.aux_out) {
+            float* q = g.aux_out + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = quick_gelu(v[r]);
+        } else if (g.act == 2) {
+          const float* q = g.aux_in + base;
+          float u[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * ldc];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad(u[r]);
+        }
+        if (g.residual) {
+          const float* q = g.residual + (size_t)mb * g.ldres + n;
+          float u[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * g.ldres];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += u[r];
+        }
+        float* q = g.C + base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + fr;
+    if (n >= N) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (m < M) epilogue_store(g, patches, m, n, acc[i][j][r], lora_mfma);
+      }
+    }
+  }
+}
+
+
 // Tile order shared by both kernels: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
 // XCD, speed only); every XCD gets a CONTIGUOUS run of the unit list.
 __device__ __forceinline__ int xcd_contiguous_unit() {
