@@ -120,6 +120,13 @@ int clipfs_layernorm_fwd(const float* x, int ldx, const float* gamma, const floa
 int clipfs_layernorm_bwd(const float* dy, const float* x, int ldx, const float* gamma, const float* mean,
                          const float* rstd, const float* dres, float* dx, int lddx, int rows, int width,
                          void* stream);
+/* fp16 storage mode: the same kernels writing an f16 copy of the result [rows, width] for the GEMM that consumes it
+ * (y16 / dx16 may be NULL; in the forward y may be NULL when only the f16 operand is needed). */
+int clipfs_layernorm_fwd_f16(const float* x, int ldx, const float* gamma, const float* beta, float* y, void* y16,
+                             float* mean, float* rstd, int rows, int width, float eps, void* stream);
+int clipfs_layernorm_bwd_f16(const float* dy, const float* x, int ldx, const float* gamma, const float* mean,
+                             const float* rstd, const float* dres, float* dx, void* dx16, int lddx, int rows, int width,
+                             void* stream);
 
 /* ------------------------------------------------------------- attention --
  * qkv [B*L, 3*d] (q | k | v, head h at columns h*64..), out [B*L, d] heads merged.
@@ -142,11 +149,12 @@ size_t clipfs_attention_lse_floats(int batch, int seq, int heads);
 /* fp16 storage mode (cfg-5), seq <= 288: the same function with both contractions on
  * v_mfma_f32_32x32x16_f16 (operands rounded to f16 in the staging path; softmax statistics, accumulators and
  * outputs fp32).  lse as above (may be NULL when no backward follows). */
-int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal,
-                             void* stream);
-/* dqkv from (qkv, dout, out, lse) of clipfs_attention_f16_fwd; work: batch*heads*seq floats (D_i = dO_i . O_i). */
+int clipfs_attention_f16_fwd(const float* qkv, float* out, void* out16, float* lse, int batch, int seq, int heads,
+                             int causal, void* stream);
+/* dqkv from (qkv, dout, out, lse) of clipfs_attention_f16_fwd; work: batch*heads*seq floats (D_i = dO_i . O_i).
+ * out16 / dqkv16 (may be NULL): f16 copies of out / dqkv, the A operands of the GEMMs that follow. */
 int clipfs_attention_f16_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv,
-                             float* work, int batch, int seq, int heads, int causal, void* stream);
+                             void* dqkv16, float* work, int batch, int seq, int heads, int causal, void* stream);
 
 /* ------------------------------------------------------------------ LoRA --
  * t[m, s*r + j] = sum_k drop_s(x)[m,k] * A[s*r + j, k]       (the "down" half of

@@ -112,7 +112,8 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // forward
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                                float* __restrict__ lse, int L, int H, int causal) {
+                                                                float* __restrict__ lse, int L, int H, int causal,
+                                                                _Float16* __restrict__ out16) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int Lp = (L + 31) & ~31, TP = Lp + 4;
   _Float16* sK = reinterpret_cast<_Float16*>(smem_raw);  // [Lp][AF_ROW]
@@ -184,6 +185,9 @@ __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __r
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = o[t][4 * g4 + j] * inv;
           *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g4) = v;
+          if (out16)
+            *reinterpret_cast<f16x4*>(out16 + ((size_t)b * L + q_tok) * d + h * AF_HD + 4 * fh + 32 * t + 8 * g4) =
+                f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         }
       if (lse && fh == 0) lse[((size_t)b * H + h) * L + q_tok] = (m + log2f(l)) * (1.f / AF_LOG2E);
     }
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* _
                                                                   const float* __restrict__ dout,
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ lse, float* __restrict__ dqkv,
-                                                                  float* __restrict__ Dbuf, int L, int H, int causal) {
+                                                                  float* __restrict__ Dbuf, int L, int H, int causal,
+                                                                  _Float16* __restrict__ dqkv16) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int Lp = (L + 31) & ~31, TP = Lp + 4;
   _Float16* sK = reinterpret_cast<_Float16*>(smem_raw);
@@ -269,6 +274,9 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* _
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[t][4 * g4 + j];
           *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g4) = v;
+          if (dqkv16)
+            *reinterpret_cast<f16x4*>(dqkv16 + ((size_t)b * L + q_tok) * ld + h * AF_HD + 4 * fh + 32 * t + 8 * g4) =
+                f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
         }
     }
   }
@@ -283,7 +291,8 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
                                                                    const float* __restrict__ dout,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ Dbuf,
-                                                                   float* __restrict__ dqkv, int L, int H, int causal) {
+                                                                   float* __restrict__ dqkv, int L, int H, int causal,
+                                                                   _Float16* __restrict__ dqkv16) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int Lp = (L + 31) & ~31, TP = Lp + 4;
   _Float16* sQ = reinterpret_cast<_Float16*>(smem_raw);
@@ -361,6 +370,11 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
           }
           *reinterpret_cast<f32x4*>(kp + 32 * t + 8 * g4) = k4;
           *reinterpret_cast<f32x4*>(vp + 32 * t + 8 * g4) = v4;
+          if (dqkv16) {
+            _Float16* k16 = dqkv16 + ((size_t)b * L + k_tok) * ld + d + h * AF_HD + 4 * fh + 32 * t + 8 * g4;
+            *reinterpret_cast<f16x4*>(k16) = f16x4{(_Float16)k4[0], (_Float16)k4[1], (_Float16)k4[2], (_Float16)k4[3]};
+            *reinterpret_cast<f16x4*>(k16 + d) = f16x4{(_Float16)v4[0], (_Float16)v4[1], (_Float16)v4[2], (_Float16)v4[3]};
+          }
         }
     }
   }
@@ -386,8 +400,8 @@ static int af_threads(int seq, int max_waves) {
   return 64 * (tiles < max_waves ? tiles : max_waves);
 }
 
-extern "C" int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads,
-                                        int causal, void* stream) {
+extern "C" int clipfs_attention_f16_fwd(const float* qkv, float* out, void* out16, float* lse, int batch, int seq,
+                                        int heads, int causal, void* stream) {
   CLIPFS_CHECK(check_af(qkv, out, batch, seq, heads));
   static bool attr = false;
   if (!attr) {
@@ -396,13 +410,13 @@ extern "C" int clipfs_attention_f16_fwd(const float* qkv, float* out, float* lse
     attr = true;
   }
   hipLaunchKernelGGL(attention_f16_fwd_kernel, dim3(batch * heads), dim3(af_threads(seq, 5)), af_lds_bytes(seq, 1, 1),
-                     (hipStream_t)stream, qkv, out, lse, seq, heads, causal);
+                     (hipStream_t)stream, qkv, out, lse, seq, heads, causal, reinterpret_cast<_Float16*>(out16));
   return launch_status();
 }
 
 extern "C" int clipfs_attention_f16_bwd(const float* qkv, const float* dout, const float* out, const float* lse,
-                                        float* dqkv, float* work, int batch, int seq, int heads, int causal,
-                                        void* stream) {
+                                        float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads,
+                                        int causal, void* stream) {
   CLIPFS_CHECK(check_af(qkv, dqkv, batch, seq, heads));
   CLIPFS_REQUIRE(dout && out && lse && work, "attention_f16_bwd: null pointer");
   static bool attr = false;
@@ -416,10 +430,10 @@ extern "C" int clipfs_attention_f16_bwd(const float* qkv, const float* dout, con
   const int threads = af_threads(seq, 9);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attention_f16_bwd_q_kernel, dim3(batch * heads), dim3(threads), af_lds_bytes(seq, 2, 1), st, qkv,
-                     dout, out, lse, dqkv, work, seq, heads, causal);
+                     dout, out, lse, dqkv, work, seq, heads, causal, reinterpret_cast<_Float16*>(dqkv16));
   CLIPFS_CHECK(launch_status());
   const size_t lds_kv = af_lds_bytes(seq, 2, 2) + 2 * (size_t)((seq + 31) & ~31) * sizeof(float);
   hipLaunchKernelGGL(attention_f16_bwd_kv_kernel, dim3(batch * heads), dim3(threads), lds_kv, st, qkv, dout, lse, work,
-                     dqkv, seq, heads, causal);
+                     dqkv, seq, heads, causal, reinterpret_cast<_Float16*>(dqkv16));
   return launch_status();
 }

@@ -5,13 +5,16 @@
 
 namespace clipfs {
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
 constexpr int LN_MAX_CHUNKS = 8;  // 8 * 64 lanes * 4 floats = width <= 2048
 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int ldx,  // x may alias y (in place)
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int rows, int width, float eps) {
+                                                            int rows, int width, float eps,
+                                                            _Float16* __restrict__ y16 = nullptr) {  // optional f16 copy (or only output)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int 
     }
   }
   const float rstd = 1.f / sqrtf(wave_sum(q) / (float)width + eps);
-  float4* yr = reinterpret_cast<float4*>(y + (size_t)row * width);
+  float4* yr = y ? reinterpret_cast<float4*>(y + (size_t)row * width) : nullptr;
+  f16x4* yh = y16 ? reinterpret_cast<f16x4*>(y16 + (size_t)row * width) : nullptr;
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
@@ -51,7 +55,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int 
       o.y = (v[i].y - mean) * rstd * g.y + b.y;
       o.z = (v[i].z - mean) * rstd * g.z + b.z;
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
-      yr[c] = o;
+      if (yr) yr[c] = o;
+      if (yh) yh[c] = f16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
     }
   }
   if (mean_out && lane == 0) {
@@ -65,7 +70,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean_in,
                                                             const float* __restrict__ rstd_in,
                                                             const float* dres, float* dx,  // may alias (in-place residual add)
-                                                            int lddx, int rows, int width) {
+                                                            int lddx, int rows, int width,
+                                                            _Float16* __restrict__ dx16 = nullptr) {  // optional f16 copy [rows, width]
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   const float c2 = wave_sum(s2) / (float)width;
   float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * lddx);
   const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * lddx) : nullptr;
+  f16x4* dxh = dx16 ? reinterpret_cast<f16x4*>(dx16 + (size_t)row * width) : nullptr;
 #pragma unroll
   for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
     const int c = lane + 64 * i;
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.w += r.w;
       }
       dxr[c] = o;
+      if (dxh) dxh[c] = f16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
     }
   }
 }
@@ -222,5 +230,32 @@ extern "C" int clipfs_l2norm_bwd(const float* dy, const float* y, const float* i
                  "l2norm_bwd: null or misaligned pointer");
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx,
                      rows, width);
+  return launch_status();
+}
+
+// fp16 storage mode: the same kernels with an f16 copy of the result for the GEMM that consumes it (y / the fp32
+// result may be NULL in the forward when only the f16 operand is needed).
+extern "C" int clipfs_layernorm_fwd_f16(const float* x, int ldx, const float* gamma, const float* beta, float* y, void* y16,
+                                        float* mean, float* rstd, int rows, int width, float eps, void* stream) {
+  CLIPFS_CHECK(check_rows("layernorm_fwd_f16", rows, width));
+  CLIPFS_REQUIRE(x && gamma && beta && (y || y16), "layernorm_fwd_f16: null pointer");
+  CLIPFS_REQUIRE((mean == nullptr) == (rstd == nullptr), "layernorm_fwd_f16: mean and rstd must both be given or both NULL");
+  CLIPFS_REQUIRE(ldx >= width && (ldx & 3) == 0 && aligned16(x) && (!y || aligned16(y)) && (!y16 || aligned16(y16)) &&
+                     aligned16(gamma) && aligned16(beta), "layernorm_fwd_f16: alignment");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                     y, mean, rstd, rows, width, eps, reinterpret_cast<_Float16*>(y16));
+  return launch_status();
+}
+
+extern "C" int clipfs_layernorm_bwd_f16(const float* dy, const float* x, int ldx, const float* gamma, const float* mean,
+                                        const float* rstd, const float* dres, float* dx, void* dx16, int lddx, int rows,
+                                        int width, void* stream) {
+  CLIPFS_CHECK(check_rows("layernorm_bwd_f16", rows, width));
+  CLIPFS_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd_f16: null pointer");
+  CLIPFS_REQUIRE(ldx >= width && (ldx & 3) == 0 && lddx >= width && (lddx & 3) == 0 && aligned16(x) && aligned16(dy) &&
+                     aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)) && (!dx16 || aligned16(dx16)),
+                 "layernorm_bwd_f16: alignment");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, ldx, gamma,
+                     mean, rstd, dres, dx, lddx, rows, width, reinterpret_cast<_Float16*>(dx16));
   return launch_status();
 }

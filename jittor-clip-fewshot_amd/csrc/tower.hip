@@ -93,9 +93,10 @@ enum GemmChain { CHAIN_NONE = 0, CHAIN_OUT16 = 1, CHAIN_IN16 = 2 };
 
 // chain: CHAIN_OUT16 = the result is only the next GEMM's A operand: in fp16 mode write it as f16 alone;
 //        CHAIN_IN16  = A is the previous GEMM's CHAIN_OUT16 result.
+// a16_ready: f16 image of A written by the producing kernel (LayerNorm / attention); NULL = convert here.
 static int gemm(const float* A, const float* B, const void* Bp, float* C, int M, int N, int K, const float* bias,
                 const float* res, int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r,
-                int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE) {
+                int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE, const void* a16_ready = nullptr) {
   clipfs_gemm_args a = {};
   a.B_planes = Bp;
   a.b_format = g_b_format;
@@ -109,6 +110,8 @@ static int gemm(const float* A, const float* B, const void* Bp, float* C, int M,
   if (g_b_format == 2 && Bp && g_a16 && (K % 32) == 0 && (!lt || (segw % 128 == 0 && r <= 16))) {
     if (chain & CHAIN_IN16) {
       a.A_f16 = g_c16;
+    } else if (a16_ready) {
+      a.A_f16 = a16_ready;  // the producing kernel already wrote the f16 image
     } else {
       CLIPFS_CHECK(clipfs_convert_f16(A, g_a16, (size_t)M * K, st));
       a.A_f16 = g_a16;
@@ -168,25 +171,39 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
     const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
     const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
 
-    CLIPFS_CHECK(clipfs_layernorm_fwd(x_in, d, b.ln1_g, b.ln1_b, h1, train ? sv + SL.stat1 : nullptr,
-                                      train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
+    // fp16 storage mode: producers write the f16 image of every GEMM operand next to (or instead of) the fp32 tensor
+    void* h16 = g_a16;                                                        // [M, d] halves: ln1 / attention / ln2 / dx
+    void* dqkv16 = g_a16 ? (void*)((char*)g_a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
+    (void)dqkv16;
+    if (h16)
+      CLIPFS_CHECK(clipfs_layernorm_fwd_f16(x_in, d, b.ln1_g, b.ln1_b, h1, h16, train ? sv + SL.stat1 : nullptr,
+                                            train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
+    else
+      CLIPFS_CHECK(clipfs_layernorm_fwd(x_in, d, b.ln1_g, b.ln1_b, h1, train ? sv + SL.stat1 : nullptr,
+                                        train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
     if (qkv_mask)
       CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, st));
     CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
-                      b.lora_b_qkv, r, 3, d, t->lora_scale, st));
-    if (f16_attention(t))
-      CLIPFS_CHECK(clipfs_attention_f16_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
-    else
+                      b.lora_b_qkv, r, 3, d, t->lora_scale, st, CHAIN_NONE, h16));
+    const void* att16 = nullptr;
+    if (f16_attention(t)) {
+      CLIPFS_CHECK(clipfs_attention_f16_fwd(qkv, att, h16, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
+      att16 = h16;
+    } else
       CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
     if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, st));
     CLIPFS_CHECK(gemm(att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
-                      1, d, t->lora_scale, st));
+                      1, d, t->lora_scale, st, CHAIN_NONE, att16));
     float* h2 = scratch + SC.h;
-    CLIPFS_CHECK(clipfs_layernorm_fwd(x_mid, d, b.ln2_g, b.ln2_b, h2, train ? sv + SL.stat2 : nullptr,
-                                      train ? sv + SL.stat2 + M : nullptr, M, d, 1e-5f, st));
+    if (h16)  // only the f16 image is consumed (by the c_fc GEMM)
+      CLIPFS_CHECK(clipfs_layernorm_fwd_f16(x_mid, d, b.ln2_g, b.ln2_b, nullptr, h16, train ? sv + SL.stat2 : nullptr,
+                                            train ? sv + SL.stat2 + M : nullptr, M, d, 1e-5f, st));
+    else
+      CLIPFS_CHECK(clipfs_layernorm_fwd(x_mid, d, b.ln2_g, b.ln2_b, h2, train ? sv + SL.stat2 : nullptr,
+                                        train ? sv + SL.stat2 + M : nullptr, M, d, 1e-5f, st));
     float* gbuf = scratch + SC.big;
     CLIPFS_CHECK(gemm(h2, b.w_fc, b.w_fc_p, gbuf, M, 4 * d, d, b.b_fc, nullptr, 1, train ? sv + SL.u : nullptr, nullptr, nullptr,
-                      nullptr, 0, 0, 0, 0.f, st, CHAIN_OUT16));
+                      nullptr, 0, 0, 0, 0.f, st, CHAIN_OUT16, h16));
     CLIPFS_CHECK(gemm(gbuf, b.w_pr, b.w_pr_p, x_next, M, d, 4 * d, b.b_pr, x_mid, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
                       0.f, st, CHAIN_IN16));
   }
@@ -207,6 +224,9 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
   g_a16 = t->weight_format == 2 ? scratch + SC.a16 : nullptr;
   g_c16 = t->weight_format == 2 ? scratch + SC.c16 : nullptr;
   const uint64_t seed = t->dropout_seed;
+  void* h16 = g_a16;                                                           // f16 image of dx (then of d ln-out ...)
+  void* dqkv16 = g_a16 ? (void*)((char*)g_a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
+  if (h16) CLIPFS_CHECK(clipfs_convert_f16(dx, h16, (size_t)M * d, st));       // later images come from LayerNorm backward
   for (int l = t->layers - 1; l >= 0; --l) {
     const clipfs_block& b = t->blocks[l];
     const float* sv = saved + (size_t)l * SL.total;
@@ -224,39 +244,50 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     float* work = scratch + SC.work;
     // MLP: du = (dx Wpr) * gelu'(u) ; dh2 = du Wfc ; dx += LN2'(dh2)
     CLIPFS_CHECK(gemm(dx, b.w_pr_t, b.w_pr_t_p, du, M, 4 * d, d, nullptr, nullptr, 2, nullptr, sv + SL.u, nullptr, nullptr, 0, 0, 0,
-                      0.f, st, CHAIN_OUT16));
+                      0.f, st, CHAIN_OUT16, h16));
     CLIPFS_CHECK(gemm(du, b.w_fc_t, b.w_fc_t_p, dh, M, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
                       st, CHAIN_IN16));
-    CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, d, M, d,
-                                      st));
+    if (h16)
+      CLIPFS_CHECK(clipfs_layernorm_bwd_f16(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, h16, d,
+                                            M, d, st));
+    else
+      CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, d, M, d,
+                                        st));
     // attention output projection
     CLIPFS_CHECK(gemm(dx, b.w_o_t, b.w_o_t_p, datt, M, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
-                      st));
+                      st, CHAIN_NONE, h16));
     if (lora_o) {
       CLIPFS_REQUIRE(b.g_lora_a_o && b.g_lora_b_o, "tower_bwd: block %d o-LoRA gradient slots missing", l);
       CLIPFS_CHECK(clipfs_lora_bwd(dx, sv + SL.att, sv + SL.t_o, b.lora_a_o, b.lora_b_o, dt, b.g_lora_a_o, b.g_lora_b_o,
                                    datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, work, st));
     }
     // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
-    if (f16_attention(t))
-      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
-                                            t->causal, st));
-    else
+    const void* dqkv16_ready = nullptr;
+    if (f16_attention(t)) {
+      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dqkv16, dh, batch, t->seq,
+                                            t->heads, t->causal, st));
+      dqkv16_ready = dqkv16;
+    } else
       CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
                                         t->causal, st));
     const bool need_dx = !(l == 0 && stop_at_input);
     if (need_dx)
       CLIPFS_CHECK(gemm(dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
-                        0.f, st));
+                        0.f, st, CHAIN_NONE, dqkv16_ready));
     if (qkv_mask) {
       CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);
       CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
                                    b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
                                    t->lora_dropout, seed, ds, work, st));
     }
-    if (need_dx)
-      CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_in, d, b.ln1_g, sv + SL.stat1, sv + SL.stat1 + M, dx, dx, d, M, d,
-                                        st));
+    if (need_dx) {
+      if (h16)
+        CLIPFS_CHECK(clipfs_layernorm_bwd_f16(dh, sv + SL.x_in, d, b.ln1_g, sv + SL.stat1, sv + SL.stat1 + M, dx, dx, h16, d,
+                                              M, d, st));
+      else
+        CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_in, d, b.ln1_g, sv + SL.stat1, sv + SL.stat1 + M, dx, dx, d, M, d,
+                                          st));
+    }
   }
   return CLIPFS_OK;
 }
