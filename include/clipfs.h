@@ -84,6 +84,8 @@ typedef struct clipfs_gemm_args {
   const void* A_f16;       /* optional f16 copy of A [M,K] (ld = lda): with b_format 2 selects the f16 x f16 kernel
                               (operands stream HBM -> LDS -> MFMA untouched); A may then be NULL */
   void* C_f16;             /* f16 x f16 kernel only: also (or, with C == NULL, only) write the result as f16, ld = ldc */
+  int aux_f16;             /* f16 x f16 kernel only: aux_out / aux_in hold f16 values (fp16 storage of the saved
+                              pre-activation), ld = ldc */
 } clipfs_gemm_args;
 int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
 /* Products with few output tiles (small per-rank batches) are cut along K into `clipfs_gemm_splits` slices

@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
         ("lora_scale", C.c_float),
         ("a_mode", C.c_int), ("img_res", C.c_int), ("patch", C.c_int), ("out_tokens", C.c_int),
         ("B_planes", C.c_void_p), ("b_format", C.c_int), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t),
-        ("A_f16", C.c_void_p), ("C_f16", C.c_void_p),
+        ("A_f16", C.c_void_p), ("C_f16", C.c_void_p), ("aux_f16", C.c_int),
     ]
 
 

@@ -31,7 +31,7 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
             act: int = 0, aux_out=None, aux_in=None, alpha: float = 1.0, lora_t=None, lora_b=None,
             lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True, b_planes=None,
-            a16: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+            a16: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None, only16: bool = False) -> torch.Tensor:
     """out = epi(alpha * a @ b.T); a [M,K], b [N,K].  ``a16`` (f16 [M,K]) with f16 ``b_planes`` selects the
     f16 x f16 kernel (``a`` may then be None); ``out16`` (f16 [M,N]) receives an f16 copy of the result."""
     if a is not None:
@@ -40,10 +40,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     M, K = (a16 if a is None else a).shape
     N = b.shape[0]
     assert b.shape[1] == K
-    if out is None:
+    if out is None and not only16:
         out = torch.empty(M, N, device=b.device, dtype=torch.float32)
     g = GemmArgs()
-    g.A, g.B, g.C = _p(a), _p(b), _p(out)
+    g.A, g.B, g.C = _p(a), _p(b), (None if only16 else _p(out))
     if a16 is not None:
         assert a16.dtype == torch.float16 and a16.is_contiguous() and tuple(a16.shape) == (M, K)
         g.A_f16 = _p(a16)
@@ -76,7 +76,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
         ws = torch.empty(nws, device=b.device, dtype=torch.float32)
         g.workspace, g.workspace_floats = _p(ws), nws
     check(lib.clipfs_gemm_nt(C.byref(g), _stream()), "gemm_nt")
-    return out
+    return out16 if only16 else out
 
 
 def split_bf16(w: torch.Tensor) -> torch.Tensor:

@@ -416,7 +416,7 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
                          a.lora_seg_width * a.lora_nseg >= a.N, "gemm f16: lora rank <= 16 and segment width %% 128 required");
     return gemm_f16_dispatch(a, (hipStream_t)stream);
   }
-  CLIPFS_REQUIRE(!a.C_f16, "gemm: C_f16 is an output of the f16 x f16 kernel only");
+  CLIPFS_REQUIRE(!a.C_f16 && !a.aux_f16, "gemm: C_f16 / aux_f16 belong to the f16 x f16 kernel only");
   CLIPFS_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
   CLIPFS_REQUIRE((a.K & 3) == 0 && (a.ldb & 3) == 0 && aligned16(a.B), "gemm: K and ldb must be multiples of 4, B 16-byte aligned");
   CLIPFS_REQUIRE(a.ldb >= a.K && a.ldc >= a.N, "gemm: leading dimension too small");

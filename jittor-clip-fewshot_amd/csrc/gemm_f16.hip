@@ -22,6 +22,17 @@ namespace clipfs {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// QuickGELU and its derivative with v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division of common.h: at
+// K = 1024 the 128 activations per lane of a 256x128 tile cost as many cycles as a third of the K loop.
+__device__ __forceinline__ float fast_sigmoid_1702(float u) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * u));
+}
+__device__ __forceinline__ float quick_gelu_fast(float u) { return u * fast_sigmoid_1702(u); }
+__device__ __forceinline__ float quick_gelu_grad_fast(float u) {
+  const float sg = fast_sigmoid_1702(u);
+  return sg * (1.f + 1.702f * u * (1.f - sg));
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -187,6 +198,68 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
   // Row offsets inside a 32x32 tile: (r & 3) + 8 (r >> 2) + 4 fh.  Every option is a wave-uniform branch around a
   // 16-element pass so the common cases stay straight-line.
   const int ldc = g.ldc;
+  if (m0 + BM <= Mend && n0 + BN <= N) {  // whole tile inside the problem: no predicates, loads of a pass issued together
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + fr;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+        const size_t base = (size_t)mb * ldc + n;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
+        if (g.act == 1) {
+          if (g.aux_out) {
+            if (g.aux_f16) {
+              _Float16* q = reinterpret_cast<_Float16*>(g.aux_out) + base;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
+            } else {
+              float* q = g.aux_out + base;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = quick_gelu_fast(v[r]);
+        } else if (g.act == 2) {
+          float u[16];
+          if (g.aux_f16) {
+            const _Float16* q = reinterpret_cast<const _Float16*>(g.aux_in) + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = (float)q[((r & 3) + 8 * (r >> 2)) * ldc];
+          } else {
+            const float* q = g.aux_in + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * ldc];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad_fast(u[r]);
+        }
+        if (g.residual) {
+          const float* q = g.residual + (size_t)mb * g.ldres + n;
+          float u[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * g.ldres];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += u[r];
+        }
+        if (g.C) {
+          float* q = g.C + base;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+        }
+        if (p.C16) {
+          _Float16* q = p.C16 + base;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / 2) + j * 32 + fr;
@@ -204,18 +277,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
       for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
       if (g.act == 1) {
         if (g.aux_out) {
-          float* q = g.aux_out + base;
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+            if (ok >> r & 1) {
+              const size_t o = base + (size_t)((r & 3) + 8 * (r >> 2)) * ldc;
+              if (g.aux_f16)
+                reinterpret_cast<_Float16*>(g.aux_out)[o] = (_Float16)v[r];
+              else
+                g.aux_out[o] = v[r];
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = quick_gelu(v[r]);
+        for (int r = 0; r < 16; ++r) v[r] = quick_gelu_fast(v[r]);
       } else if (g.act == 2) {
-        const float* q = g.aux_in + base;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (ok >> r & 1) v[r] *= quick_gelu_grad(q[((r & 3) + 8 * (r >> 2)) * ldc]);
+          if (ok >> r & 1) {
+            const size_t o = base + (size_t)((r & 3) + 8 * (r >> 2)) * ldc;
+            v[r] *= quick_gelu_grad_fast(g.aux_f16 ? (float)reinterpret_cast<const _Float16*>(g.aux_in)[o] : g.aux_in[o]);
+          }
       }
       if (g.residual) {
         const float* q = g.residual + (size_t)mb * g.ldres + n;

@@ -32,7 +32,7 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
   L.t_o = o;   o += al4(M * r);
   L.x_mid = o; o += al4(M * d);
   L.stat2 = o; o += al4(2 * M);
-  L.u = o;     o += al4(M * 4 * d);
+  L.u = o;     o += al4(t->weight_format == 2 ? M * 2 * d : M * 4 * d);  // fp16 mode: pre-activation saved as f16
   L.total = o;
   return L;
 }
@@ -120,6 +120,7 @@ static int gemm(const float* A, const float* B, const void* Bp, float* C, int M,
       a.C_f16 = g_c16;
       a.C = nullptr;
     }
+    a.aux_f16 = 1;  // fp16 storage of the saved pre-activation (only the f16 x f16 GEMMs read or write it)
   }
   return clipfs_gemm_nt(&a, st);
 }

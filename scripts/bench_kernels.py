@@ -117,9 +117,10 @@ def f16_bench():
         t0 = timeit(lambda: ops.gemm_nt(a, b, out, b_planes=b16))
         t1 = timeit(lambda: ops.gemm_nt(None, b, out, b_planes=b16, a16=a16))
         t2 = timeit(lambda: ops.gemm_nt(None, b, out, b_planes=b16, a16=a16, out16=out16))
+        t3 = timeit(lambda: ops.gemm_nt(None, b, None, b_planes=b16, a16=a16, out16=out16, only16=True))
         fl = 2 * M * N * K
         print(f"gemm {name:7s} f32A {t0*1e6:8.1f} us {fl/t0/1e12:7.1f} TF | f16A {t1*1e6:8.1f} us {fl/t1/1e12:7.1f} TF "
-              f"| +C16 {t2*1e6:8.1f} us {fl/t2/1e12:7.1f} TF", flush=True)
+              f"| +C16 {t2*1e6:8.1f} us {fl/t2/1e12:7.1f} TF | C16 only {t3*1e6:8.1f} us {fl/t3/1e12:7.1f} TF", flush=True)
 
 
 if __name__ == "__main__" and "--f16" in sys.argv:
