@@ -11,6 +11,8 @@
     stage2_loss       slow_pace.py:1622-1688 the stage-2 objective without the MoCo branch
     Stage2Trainer     slow_pace.py:1590-1697 the loop body (prompt ctx + VPT + head, AdamW + cosine LR)
     load_lora_swa     slow_pace.py:736-816   average of several saved LoRA files
+    pre_load_zs       slow_pace.py:1435-1477 cached zero-shot MTA features of the training images
+    PromptQueue       README.md:22           queue of learned prompt features blended with the hand-written ones
 
 The MoCo-v3 auxiliary branch (moco_model / Moco_Adapter, slow_pace.py:1677-1680) stays out of scope (SURVEY.md
 section 2 row 17): ``stage2_loss`` is ``sim_ce + L_SCL + lp_ce``, i.e. :1688 without ``loss_aux``.
@@ -299,6 +301,44 @@ def stage2_loss(image_features: torch.Tensor, text_features: torch.Tensor, targe
     terms = {"sim_ce": sim_ce, "scl_text": loss_scl_text, "scl_image": loss_scl_image, "scl_logits": loss_scl_logits,
              "lp_ce": lp_ce}
     return loss, terms, cos
+
+
+@torch.no_grad()
+def pre_load_zs(clip_model_zs, views: torch.Tensor, text_features_zs: torch.Tensor) -> torch.Tensor:
+    """slow_pace.py:1435-1454 (and its twin :1456-1477): the cached zero-shot MTA feature of every training image --
+    ``views`` [n_img, V, 3, R, R] (view 0 = the centre preprocess, the rest the loader's random crops; build them on the
+    GPU with ``tta.make_tta_views``), ``text_features_zs`` [C, d] the zero-shot classifier.  Per image: encode the V views,
+    L2-normalise, ``solve_mta`` -> the mode feature (:1445-1449).  Returns [n_img, d] (the reference pickles the list as
+    ``features_zs1.pkl``; Stage2Trainer takes the tensor directly)."""
+    import ood
+    _, mode = ood.mta_scores(clip_model_zs, views, text_features_zs, want_mode=True)
+    return mode
+
+
+class PromptQueue:
+    """README.md:22 ("learning-pace control"): every N epochs the learned prompt-derived class features are pushed into
+    a fixed-length queue (the oldest entry drops out) and the queue is averaged with the hand-written / LLM-generated
+    prompt features.  The reference ships the description but not this code (its eval path fuses logits of the prompt and
+    hand-written classifiers instead, test.py:1729-1742): this is the build's restatement, kept deliberately minimal --
+    ``push`` stores unit-norm [C, d] text features, ``blend`` returns normalise(w * mean(queue) + (1 - w) * hand)."""
+
+    def __init__(self, maxlen: int = 4):
+        from collections import deque
+        self.q = deque(maxlen=maxlen)
+
+    def push(self, text_features: torch.Tensor) -> None:
+        self.q.append(E.l2_normalize(text_features.detach().float()).clone())
+
+    def __len__(self) -> int:
+        return len(self.q)
+
+    @torch.no_grad()
+    def blend(self, hand_features: torch.Tensor, weight: float = 0.5) -> torch.Tensor:
+        hand = E.l2_normalize(hand_features.float())
+        if not self.q:
+            return hand
+        mean = torch.stack(list(self.q)).mean(0)
+        return E.l2_normalize(weight * mean + (1.0 - weight) * hand)
 
 
 class Stage2Trainer:

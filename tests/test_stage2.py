@@ -223,3 +223,39 @@ def test_load_lora_swa_averages_saved_files(monkeypatch, tmp_path):
         S.load_lora_swa(T._args("tiny", r=8), layers, str(folder))
     with pytest.raises(FileNotFoundError):
         S.load_lora_swa(args, layers, str(folder) + ".missing")
+
+
+@pytest.mark.gpu
+def test_pre_load_zs_and_prompt_queue(monkeypatch):
+    """slow_pace.py:1435-1454: cached zero-shot MTA features = per image solve_mta(mode) over its views (oracle per
+    image); PromptQueue (README.md:22): fixed-length queue, blend = normalise(w mean(queue) + (1 - w) hand)."""
+    import test_engine_gpu as T
+    import slow_pace as S
+    from clipfs import synth
+    dev = torch.device("cuda:0")
+    cfg = synth.SMALL
+    sd, model = T._build(cfg, dev)
+    model.eval()
+    n_img, V, C, d = 2, 9, 7, cfg.embed_dim
+    g = torch.Generator().manual_seed(5)
+    R = cfg.image_resolution
+    base = torch.randn(n_img, 1, 3, R, R, generator=g)
+    views = (base + 0.3 * torch.randn(n_img, V, 3, R, R, generator=g)).contiguous()
+    text = O.l2_normalize(torch.randn(C, d, generator=g, dtype=torch.float64)).float()
+    feats = S.pre_load_zs(model, views.to(dev), text.to(dev))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    assert feats.shape == (n_img, d)
+    for i in range(n_img):
+        f = O.l2_normalize(O.encode_image(sd64, views[i].double())).float()
+        want = O.solve_mta(f, text.t(), return_mode=True)
+        assert (feats[i:i + 1].cpu().double() - want.double()).abs().max() < 5e-5
+    q = S.PromptQueue(maxlen=2)
+    hand = torch.randn(C, d, generator=g)
+    assert torch.allclose(q.blend(hand.to(dev)).cpu(), O.l2_normalize(hand.double()).float(), atol=1e-6)
+    fs = [torch.randn(C, d, generator=g) for _ in range(3)]
+    for f in fs:
+        q.push(f.to(dev))
+    assert len(q) == 2  # the oldest entry dropped out
+    mean = torch.stack([O.l2_normalize(f.double()) for f in fs[1:]]).mean(0)
+    want = O.l2_normalize(0.25 * mean + 0.75 * O.l2_normalize(hand.double()))
+    assert (q.blend(hand.to(dev), weight=0.25).cpu().double() - want).abs().max() < 1e-6
