@@ -318,10 +318,18 @@ static int launch(const GemmParams& p, hipStream_t stream) {
 
 using namespace clipfs;
 
-// Tile height: 64 x 128 normally; 32 x 128 when that leaves fewer than two tiles per CU (small per-rank batches).
+// Tile height: 64 x 128, or 32 x 128 when that balances the 256 CUs better.  All tiles of a launch that fits the
+// resident slots start together and share their CU's MFMA pipe, so a launch lasts ceil(tiles / 256) tile-times of
+// the busiest CU: cost = ceil(tiles / 256) * rows-per-tile, with 8 % on top for the 32-row tile (it re-reads B
+// twice as often).  Measured on the per-rank shapes of the strong-scaling run (scripts/bench_small_m.py): e.g. 600
+// tiles of 64 rows (3 vs 2.34 per CU) lose 7-9 % against 1200 tiles of 32 rows, 450 tiles of 64 rows win by 9 %.
 static inline int gemm_bm(int M, int N) {
-  const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
-  return tiles < 512 ? 32 : 64;
+  static const int force = getenv("CLIPFS_GEMM_BM") ? atoi(getenv("CLIPFS_GEMM_BM")) : 0;  // tuning aid: 32 / 64
+  if (force == 32 || force == 64) return force;
+  const long nbn = (N + 127) / 128;
+  const long t64 = (long)((M + 63) / 64) * nbn, t32 = (long)((M + 31) / 32) * nbn;
+  const double cost64 = (double)((t64 + 255) / 256) * 64.0, cost32 = (double)((t32 + 255) / 256) * 32.0 * 1.08;
+  return cost32 < cost64 ? 32 : 64;
 }
 
 // Split-K factor for a [M,N,K] product: only when even the 32 x 128 tiling leaves the 256 CUs short of work
