@@ -116,3 +116,72 @@ def test_mta_view_count_extremes(dev, V):
         from clipfs import _lib
         with pytest.raises(_lib.ClipfsError):
             ops.mta(feats[:4].to(dev).unsqueeze(0), text.to(dev))
+
+
+def _attn_ref(qkv, B, L, H, causal):
+    x = qkv.double().view(B, L, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), dtype=torch.float64).triu(1)
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, H * 64)
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(1, 1, 1, False), (1, 1, 1, True), (3, 31, 1, True), (1, 32, 3, False),
+                                          (2, 33, 1, True), (1, 64, 1, True), (1, 65, 2, False), (5, 2, 1, True)])
+def test_mfma_attention_tile_edges(dev, B, L, H, causal):
+    """fp32 MFMA attention at the 32-token tile boundaries (one token, one short tile, exactly one / two tiles, one
+    token into the next tile), odd batch*heads; forward, log-sum-exp and backward against fp64 autograd."""
+    from clipfs import ops
+    g = torch.Generator().manual_seed(L * 3 + H)
+    qkv = torch.randn(B * L, 3 * H * 64, generator=g, dtype=torch.float64).requires_grad_()
+    do = torch.randn(B * L, H * 64, generator=g, dtype=torch.float64)
+    ref = _attn_ref(qkv, B, L, H, causal)
+    (ref * do).sum().backward()
+    qd = qkv.detach().float().to(dev)
+    out, lse = ops.attention_fwd(qd, B, L, H, causal, want_lse=True)
+    assert _err(out, ref) < 2e-5
+    dq = ops.attention_bwd(qd, do.float().to(dev), B, L, H, causal, out=out, lse=lse)
+    assert _err(dq, qkv.grad) < 5e-5 * max(1.0, qkv.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("rows", [1, 15, 16, 17, 65])
+def test_mfma_lora_row_edges(dev, rows):
+    """fp32-MFMA LoRA kernels with row counts around the 16-row MFMA tile and the 64-row reduction slice."""
+    from clipfs import ops
+    width, r, nseg = 128, 16, 3
+    g = torch.Generator().manual_seed(rows)
+    R = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    x, A, Bm, dy = R(rows, width), R(nseg * r, width) * 0.1, R(nseg * width, r) * 0.1, R(rows, nseg * width)
+    xs, As, Bs = x.clone().requires_grad_(), A.clone().requires_grad_(), Bm.clone().requires_grad_()
+    t = torch.cat([xs @ As[s * r:(s + 1) * r].t() for s in range(nseg)], 1)
+    y = torch.cat([0.25 * t[:, s * r:(s + 1) * r] @ Bs[s * width:(s + 1) * width].t() for s in range(nseg)], 1)
+    y.backward(dy)
+    D = lambda v: v.detach().float().to(dev)
+    tg = ops.lora_down(D(x), D(A), r, nseg)
+    assert _err(tg, t) < 2e-5
+    dA, dB, dx = torch.zeros(nseg * r, width, device=dev), torch.zeros(nseg * width, r, device=dev), torch.zeros(rows, width, device=dev)
+    ops.lora_bwd(D(dy), D(x), tg, D(A), D(Bm), dA, dB, dx=dx, scale=0.25)
+    tol = lambda w: 2e-5 * max(1.0, w.abs().max().item())
+    assert _err(dA, As.grad) < tol(As.grad) and _err(dB, Bs.grad) < tol(Bs.grad) and _err(dx, xs.grad) < tol(xs.grad)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (255, 8, 64), (256, 136, 96), (513, 128, 1024), (33024, 128, 32)])
+def test_gemm_f16_ragged_shapes(dev, M, N, K):
+    """f16 x f16 kernel at ragged tile edges (single row, N below one tile, one row past a 256-row block, the peeled
+    tail launch of a long M) with every output kind."""
+    from clipfs import ops
+    g = torch.Generator().manual_seed(M + N)
+    a16 = torch.randn(M, K, generator=g).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    w16 = ops.to_f16(w)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = a16.float() @ w16.float().t() + bias
+    out16 = torch.empty(M, N, device=dev, dtype=torch.float16)
+    out = ops.gemm_nt(None, w, bias=bias, b_planes=w16, a16=a16, out16=out16)
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-5 * scale + 1e-5
+    assert (out16.float() - ref).abs().max().item() <= 1e-3 * scale + 1e-4
+    only = torch.empty(M, N, device=dev, dtype=torch.float16)
+    ops.gemm_nt(None, w, None, bias=bias, b_planes=w16, a16=a16, out16=only, only16=True)
+    assert torch.equal(only, out16)
