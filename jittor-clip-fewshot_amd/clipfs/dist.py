@@ -47,3 +47,17 @@ def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     if world > 1:
         dist.all_reduce(t, group=group)
     return t
+
+
+def allgather_int_rows(local: Optional[torch.Tensor], lo: int, hi: int, total: int, width: int, device,
+                       group=None) -> torch.Tensor:
+    """Integer results (top-5 labels, base/new flags) of rows [lo, hi) from every rank -> the full [total, width]
+    int32 table on every rank (the only exchange of the TTA / OOD path).  Same
+    zero-padded all-reduce as ``allgather_rows``: exact for integers, runs under RCCL and gloo."""
+    full = torch.zeros(total, width, device=device, dtype=torch.int32)
+    if hi > lo:
+        full[lo:hi].copy_(local.to(torch.int32).reshape(hi - lo, width))
+    _, world = world_info(group)
+    if world > 1:
+        dist.all_reduce(full, group=group)
+    return full

@@ -43,3 +43,30 @@ def split_ood(clip_model, views: torch.Tensor, text_features_cd: torch.Tensor) -
     logits, _ = mta_scores(clip_model, views, text_features_cd)
     pred = ops.topk(logits, 1).long().squeeze(1)
     return pred <= BASE_BOUNDARY, pred
+
+
+@torch.no_grad()
+def score_views(clip_model, views: torch.Tensor, text_features_cd: torch.Tensor):
+    """One image-tower pass over n_img * V views -> (top-5 labels [n_img, 5] int32, is_base [n_img] bool, MTA logits):
+    the scoring of ood.py:867-883 and the label list of test.py:1738 from the same features."""
+    logits, _ = mta_scores(clip_model, views, text_features_cd)
+    top5 = ops.topk(logits, 5)
+    return top5, top5[:, 0].long() <= BASE_BOUNDARY, logits
+
+
+@torch.no_grad()
+def score_images_sharded(score_fn, n_images: int, device, group=None):
+    """cfg-4 on N GPUs: source images are independent units, rank r scores images
+    [lo, hi) -- every image's views stay on one GPU, no data-path collective -- and the integer results are
+    assembled on every rank with one exchange.  ``score_fn(lo, hi)`` returns (top5 [hi - lo, 5], is_base [hi - lo])
+    for the local shard (e.g. ``lambda lo, hi: score_views(model, views[lo:hi], text)[:2]``).
+    Returns (top5 [n, 5] int32, is_base [n] bool) identical on all ranks."""
+    from clipfs import dist as D
+    rank, world = D.world_info(group)
+    lo, hi = D.shard_bounds(n_images, rank, world)
+    local = None
+    if hi > lo:
+        top5, is_base = score_fn(lo, hi)
+        local = torch.cat([top5.to(torch.int32).reshape(hi - lo, 5), is_base.to(torch.int32).reshape(hi - lo, 1)], dim=1)
+    table = D.allgather_int_rows(local, lo, hi, n_images, 6, device, group)
+    return table[:, :5].contiguous(), table[:, 5] != 0

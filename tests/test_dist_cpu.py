@@ -97,3 +97,62 @@ def test_two_rank_gloo_matches_single_process(tmp_path, shard_text):
     assert abs(float(z["loss"][0]) - loss.item()) < 1e-12
     assert np.allclose(z["grads"], want, atol=1e-12, rtol=1e-9)
     assert np.abs(want).max() > 1e-4
+
+
+# ---- cfg-4 (MTA TTA / OOD scoring) on N ranks: images sharded, integer results gathered -------------------------
+
+def _tta_inputs():
+    g = torch.Generator().manual_seed(31)
+    n_img, V, C, d = 7, 9, 380, 32   # 7 images over 3 ranks: shards of 2 / 2 / 3; C > 373 so both base and new occur
+    from oracle import clip_oracle as O
+    text = O.l2_normalize(torch.randn(C, d, generator=g, dtype=torch.float64))
+    feats = torch.randn(n_img, V, d, generator=g, dtype=torch.float64)
+    for i, c in ((1, 375), (4, 379), (6, 376), (0, 10), (3, 200)):  # views clustered around a class prototype
+        feats[i] = text[c] + 0.15 * feats[i]
+    return O.l2_normalize(feats), text
+
+
+def _oracle_scores(feats, text, lo, hi):
+    from oracle import clip_oracle as O
+    top5, base = [], []
+    for i in range(lo, hi):
+        logits = O.solve_mta(feats[i], text.t())
+        top5.append(O.jt_topk(logits, 5).reshape(1, 5))
+        base.append(bool(O.ood_is_base(logits)[0]))
+    return torch.cat(top5).to(torch.int32), torch.tensor(base)
+
+
+def _tta_rank_main(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import ood
+    feats, text = _tta_inputs()
+    calls = []
+
+    def score_fn(lo, hi):
+        calls.append((lo, hi))
+        return _oracle_scores(feats, text, lo, hi)
+
+    top5, is_base = ood.score_images_sharded(score_fn, feats.shape[0], torch.device("cpu"))
+    np.savez(os.path.join(out_dir, f"tta_{rank}.npz"), top5=top5.numpy(), base=is_base.numpy(), calls=np.array(calls))
+    dist.destroy_process_group()
+
+
+def test_tta_scoring_sharded_over_three_gloo_ranks(tmp_path):
+    """rank r scores its contiguous shard of the source images (all views of an image stay on
+    one rank), one integer exchange assembles top-5 labels and base/new flags on every rank; must equal the
+    single-process result, on every rank, with uneven shards."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jittor-clip-fewshot_amd"))
+    feats, text = _tta_inputs()
+    want_top5, want_base = _oracle_scores(feats, text, 0, feats.shape[0])
+    assert want_base.any() and not want_base.all()
+    mp.spawn(_tta_rank_main, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    seen = []
+    for r in range(3):
+        z = np.load(os.path.join(str(tmp_path), f"tta_{r}.npz"))
+        assert np.array_equal(z["top5"], want_top5.numpy()) and np.array_equal(z["base"], want_base.numpy())
+        seen += [tuple(c) for c in z["calls"]]
+    assert sorted(seen) == [(0, 2), (2, 4), (4, 7)]  # disjoint cover of the 7 images
