@@ -151,12 +151,14 @@ size_t clipfs_attention_lse_floats(int batch, int seq, int heads);
 /* fp16 storage mode (cfg-5), seq <= 288: the same function with both contractions on
  * v_mfma_f32_32x32x16_f16 (operands rounded to f16 in the staging path; softmax statistics, accumulators and
  * outputs fp32).  lse as above (may be NULL when no backward follows). */
-int clipfs_attention_f16_fwd(const float* qkv, float* out, void* out16, float* lse, int batch, int seq, int heads,
-                             int causal, void* stream);
+int clipfs_attention_f16_fwd(const void* qkv, int qkv_f16, float* out, void* out16, float* lse, int batch, int seq,
+                             int heads, int causal, void* stream);
 /* dqkv from (qkv, dout, out, lse) of clipfs_attention_f16_fwd; work: batch*heads*seq floats (D_i = dO_i . O_i).
- * out16 / dqkv16 (may be NULL): f16 copies of out / dqkv, the A operands of the GEMMs that follow. */
-int clipfs_attention_f16_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv,
-                             void* dqkv16, float* work, int batch, int seq, int heads, int causal, void* stream);
+ * out16 / dqkv16 (may be NULL): f16 copies of out / dqkv, the A operands of the GEMMs that follow.
+ * qkv_f16 != 0: qkv is an f16 tensor [B*L, 3*d] (the QKV GEMM's f16 output: fp16 storage), else fp32. */
+int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const float* dout, const float* out, const float* lse,
+                             float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads, int causal,
+                             void* stream);
 
 /* ------------------------------------------------------------------ LoRA --
  * t[m, s*r + j] = sum_k drop_s(x)[m,k] * A[s*r + j, k]       (the "down" half of

@@ -155,15 +155,17 @@ def attention_f16_fwd(qkv, batch, seq, heads, causal=False):
     """fp16-mode MFMA attention (seq <= 288): returns (out, lse)."""
     out = torch.empty(batch * seq, heads * 64, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(batch * heads * seq, device=qkv.device, dtype=torch.float32)
-    check(_lib.load().clipfs_attention_f16_fwd(_p(_f32(qkv)), _p(out), None, _p(lse), batch, seq, heads, int(causal), _stream()),
-          "attention_f16_fwd")
+    f16 = qkv.dtype == torch.float16
+    check(_lib.load().clipfs_attention_f16_fwd(_p(qkv if f16 else _f32(qkv)), int(f16), _p(out), None, _p(lse), batch, seq,
+                                               heads, int(causal), _stream()), "attention_f16_fwd")
     return out, lse
 
 
 def attention_f16_bwd(qkv, dout, out, lse, batch, seq, heads, causal=False):
-    dqkv = torch.empty_like(qkv)
+    f16 = qkv.dtype == torch.float16
+    dqkv = torch.empty(qkv.shape, device=qkv.device, dtype=torch.float32)
     work = torch.empty_like(lse)
-    check(_lib.load().clipfs_attention_f16_bwd(_p(_f32(qkv)), _p(_f32(dout)), _p(out), _p(lse), _p(dqkv), None, _p(work), batch,
+    check(_lib.load().clipfs_attention_f16_bwd(_p(qkv if f16 else _f32(qkv)), int(f16), _p(_f32(dout)), _p(out), _p(lse), _p(dqkv), None, _p(work), batch,
                                                seq, heads, int(causal), _stream()), "attention_f16_bwd")
     return dqkv
 

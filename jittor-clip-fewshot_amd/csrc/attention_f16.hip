@@ -39,9 +39,16 @@ __device__ __forceinline__ f16x8 cvt8(const f32x4& a, const f32x4& b) {
   return h;
 }
 
-// Stage `L` token rows (fp32, 64 features at `src`, row stride ld) as f16 into a row-major image and/or a transposed
+// eight consecutive features as f16: converted from fp32, or taken as they are from an f16 tensor (fp16 storage of qkv)
+__device__ __forceinline__ f16x8 load8(const float* p) {
+  return cvt8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+}
+__device__ __forceinline__ f16x8 load8(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
+
+// Stage `L` token rows (fp32 or f16, 64 features at `src`, row stride ld) as f16 into a row-major image and/or a transposed
 // image; tokens [L, Lp) are zero-filled so masked lanes multiply finite values.
-__device__ __forceinline__ void stage_head(const float* __restrict__ src, size_t ld, int L, int Lp, _Float16* rowm,
+template <typename T>
+__device__ __forceinline__ void stage_head(const T* __restrict__ src, size_t ld, int L, int Lp, _Float16* rowm,
                                            _Float16* tr) {
   const int TP = Lp + 4;
   if (rowm)  // feature chunk fastest: coalesced global reads, one ds_write_b128 per (token, chunk)
@@ -50,10 +57,7 @@ __device__ __forceinline__ void stage_head(const float* __restrict__ src, size_t
       f16x8 h;
 #pragma unroll
       for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
-      if (tok < L) {
-        const float* p = src + (size_t)tok * ld + 8 * c;
-        h = cvt8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
-      }
+      if (tok < L) h = load8(src + (size_t)tok * ld + 8 * c);
       *reinterpret_cast<f16x8*>(rowm + tok * AF_ROW + 8 * c) = h;
     }
   if (tr)  // token fastest: the eight ds_write_b16 of a lane group go to consecutive halves of one feature row
@@ -62,21 +66,18 @@ __device__ __forceinline__ void stage_head(const float* __restrict__ src, size_t
       f16x8 h;
 #pragma unroll
       for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
-      if (tok < L) {
-        const float* p = src + (size_t)tok * ld + 8 * c;
-        h = cvt8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
-      }
+      if (tok < L) h = load8(src + (size_t)tok * ld + 8 * c);
 #pragma unroll
       for (int j = 0; j < 8; ++j) tr[(8 * c + j) * TP + tok] = h[j];
     }
 }
 
 // The wave's own 32 rows as MFMA operands: frag[s] = row (t0 + lane & 31), features 16 s + 8 (lane >> 5) .. + 7.
-__device__ __forceinline__ void load_own(const float* __restrict__ src, size_t ld, int t0, int L, int lane, f16x8 (&frag)[4]) {
-  const float* p = src + (size_t)min(t0 + (lane & 31), L - 1) * ld + 8 * (lane >> 5);
+template <typename T>
+__device__ __forceinline__ void load_own(const T* __restrict__ src, size_t ld, int t0, int L, int lane, f16x8 (&frag)[4]) {
+  const T* p = src + (size_t)min(t0 + (lane & 31), L - 1) * ld + 8 * (lane >> 5);
 #pragma unroll
-  for (int s = 0; s < 4; ++s)
-    frag[s] = cvt8(*reinterpret_cast<const f32x4*>(p + 16 * s), *reinterpret_cast<const f32x4*>(p + 16 * s + 4));
+  for (int s = 0; s < 4; ++s) frag[s] = load8(p + 16 * s);
 }
 
 // acc[tile rows = other-side tokens t0.. (register index)][cols = own tokens (lane)] = other_rowmajor . own^T
@@ -111,7 +112,8 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // ---------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+template <typename TQ>
+__global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const TQ* __restrict__ qkv, float* __restrict__ out,
                                                                 float* __restrict__ lse, int L, int H, int causal,
                                                                 _Float16* __restrict__ out16) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __r
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int d = H * AF_HD;
   const size_t ld = (size_t)3 * d;
-  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
+  const TQ* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
   stage_head(q0 + d, ld, L, Lp, sK, nullptr);
   stage_head(q0 + 2 * d, ld, L, Lp, nullptr, sVt);
   __syncthreads();
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const float* __r
 // backward, pass 1: dQ (and D_i = dO_i . O_i for pass 2).  Own side = queries; K (both images) and V in LDS.
 //   S^T = K Q^T ; P^T = exp(S^T c - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - D) / 8 ; dQ^T += K^T dS^T
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* __restrict__ qkv,
+template <typename TQ>
+__global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const TQ* __restrict__ qkv,
                                                                   const float* __restrict__ dout,
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ lse, float* __restrict__ dqkv,
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* _
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int d = H * AF_HD;
   const size_t ld = (size_t)3 * d;
-  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
+  const TQ* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
   stage_head(q0 + d, ld, L, Lp, sK, sKt);
   stage_head(q0 + 2 * d, ld, L, Lp, sV, nullptr);
   __syncthreads();
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const float* _
 //   S = Q K^T ; P = exp(S c - lse) ; dP = dO V^T ; dS = P (dP - D) / 8 ; dV^T += dO^T P ; dK^T += Q^T dS
 // (rows of the MFMA result = queries, so lse and D vary with the register index: read as 4-float groups from LDS).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* __restrict__ qkv,
+template <typename TQ>
+__global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const TQ* __restrict__ qkv,
                                                                    const float* __restrict__ dout,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ Dbuf,
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const float* 
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int d = H * AF_HD;
   const size_t ld = (size_t)3 * d;
-  const float* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
+  const TQ* q0 = qkv + (size_t)b * L * ld + (size_t)h * AF_HD;
   stage_head(q0, ld, L, Lp, sQ, sQt);
   stage_head(dout + (size_t)b * L * d + (size_t)h * AF_HD, (size_t)d, L, Lp, sG, sGt);
   for (int i = threadIdx.x; i < Lp; i += (int)blockDim.x) {
@@ -400,40 +404,58 @@ static int af_threads(int seq, int max_waves) {
   return 64 * (tiles < max_waves ? tiles : max_waves);
 }
 
-extern "C" int clipfs_attention_f16_fwd(const float* qkv, float* out, void* out16, float* lse, int batch, int seq,
-                                        int heads, int causal, void* stream) {
-  CLIPFS_CHECK(check_af(qkv, out, batch, seq, heads));
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_fwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  hipLaunchKernelGGL(attention_f16_fwd_kernel, dim3(batch * heads), dim3(af_threads(seq, 5)), af_lds_bytes(seq, 1, 1),
-                     (hipStream_t)stream, qkv, out, lse, seq, heads, causal, reinterpret_cast<_Float16*>(out16));
+template <typename TQ>
+static void af_set_attrs() {
+  static bool done = false;
+  if (done) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_fwd_kernel<TQ>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_q_kernel<TQ>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_kv_kernel<TQ>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done = true;
+}
+
+template <typename TQ>
+static int af_fwd(const void* qkv, float* out, void* out16, float* lse, int batch, int seq, int heads, int causal,
+                  hipStream_t st) {
+  af_set_attrs<TQ>();
+  hipLaunchKernelGGL(attention_f16_fwd_kernel<TQ>, dim3(batch * heads), dim3(af_threads(seq, 5)), af_lds_bytes(seq, 1, 1), st,
+                     reinterpret_cast<const TQ*>(qkv), out, lse, seq, heads, causal, reinterpret_cast<_Float16*>(out16));
   return launch_status();
 }
 
-extern "C" int clipfs_attention_f16_bwd(const float* qkv, const float* dout, const float* out, const float* lse,
-                                        float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads,
-                                        int causal, void* stream) {
-  CLIPFS_CHECK(check_af(qkv, dqkv, batch, seq, heads));
-  CLIPFS_REQUIRE(dout && out && lse && work, "attention_f16_bwd: null pointer");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_q_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_kv_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+template <typename TQ>
+static int af_bwd(const void* qkv, const float* dout, const float* out, const float* lse, float* dqkv, void* dqkv16,
+                  float* work, int batch, int seq, int heads, int causal, hipStream_t st) {
+  af_set_attrs<TQ>();
   const int threads = af_threads(seq, 9);
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attention_f16_bwd_q_kernel, dim3(batch * heads), dim3(threads), af_lds_bytes(seq, 2, 1), st, qkv,
-                     dout, out, lse, dqkv, work, seq, heads, causal, reinterpret_cast<_Float16*>(dqkv16));
+  hipLaunchKernelGGL(attention_f16_bwd_q_kernel<TQ>, dim3(batch * heads), dim3(threads), af_lds_bytes(seq, 2, 1), st,
+                     reinterpret_cast<const TQ*>(qkv), dout, out, lse, dqkv, work, seq, heads, causal,
+                     reinterpret_cast<_Float16*>(dqkv16));
   CLIPFS_CHECK(launch_status());
   const size_t lds_kv = af_lds_bytes(seq, 2, 2) + 2 * (size_t)((seq + 31) & ~31) * sizeof(float);
-  hipLaunchKernelGGL(attention_f16_bwd_kv_kernel, dim3(batch * heads), dim3(threads), lds_kv, st, qkv, dout, lse, work,
-                     dqkv, seq, heads, causal, reinterpret_cast<_Float16*>(dqkv16));
+  hipLaunchKernelGGL(attention_f16_bwd_kv_kernel<TQ>, dim3(batch * heads), dim3(threads), lds_kv, st,
+                     reinterpret_cast<const TQ*>(qkv), dout, lse, work, dqkv, seq, heads, causal,
+                     reinterpret_cast<_Float16*>(dqkv16));
   return launch_status();
+}
+
+extern "C" int clipfs_attention_f16_fwd(const void* qkv, int qkv_f16, float* out, void* out16, float* lse, int batch, int seq,
+                                        int heads, int causal, void* stream) {
+  CLIPFS_CHECK(check_af(qkv, out, batch, seq, heads));
+  CLIPFS_REQUIRE(aligned16(qkv) && aligned16(out), "attention_f16_fwd: misaligned pointer");
+  return qkv_f16 ? af_fwd<_Float16>(qkv, out, out16, lse, batch, seq, heads, causal, (hipStream_t)stream)
+                 : af_fwd<float>(qkv, out, out16, lse, batch, seq, heads, causal, (hipStream_t)stream);
+}
+
+extern "C" int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const float* dout, const float* out, const float* lse,
+                                        float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads, int causal,
+                                        void* stream) {
+  CLIPFS_CHECK(check_af(qkv, dqkv, batch, seq, heads));
+  CLIPFS_REQUIRE(dout && out && lse && work, "attention_f16_bwd: null pointer");
+  CLIPFS_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(out) && aligned16(dqkv), "attention_f16_bwd: misaligned pointer");
+  return qkv_f16 ? af_bwd<_Float16>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, (hipStream_t)stream)
+                 : af_bwd<float>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, (hipStream_t)stream);
 }

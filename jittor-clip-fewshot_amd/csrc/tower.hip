@@ -12,6 +12,14 @@ namespace clipfs {
 
 static inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 
+// fp16 storage mode runs attention on the f16 MFMA kernels (attention_f16.hip; sequences up to 288 tokens)
+static inline bool f16_attention(const clipfs_tower* t) { return t->weight_format == 2 && t->seq <= 288; }
+// ... and then qkv itself is stored as f16 (written by the QKV GEMM, read by the attention kernels): needs the
+// f16 x f16 GEMM for the LoRA'd projection, i.e. a segment width that is a multiple of its 128-column tiles
+static inline bool qkv_f16(const clipfs_tower* t) {
+  return f16_attention(t) && (t->width % 128) == 0 && t->lora_r <= 16;
+}
+
 struct SavedLayout {
   size_t x_in, stat1, h1, t_qkv, qkv, att, lse, t_o, x_mid, stat2, u, total;
 };
@@ -24,7 +32,7 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
   L.stat1 = o; o += al4(2 * M);
   L.h1 = o;    o += al4(M * d);
   L.t_qkv = o; o += al4(M * 3 * r);
-  L.qkv = o;   o += al4(M * 3 * d);
+  L.qkv = o;   o += al4(qkv_f16(t) ? (M * 3 * d + 1) / 2 : M * 3 * d);  // fp16 mode: q | k | v saved as f16
   L.att = o;   o += al4(M * d);
   // log-sum-exp rows: the long-sequence fp32 kernels (0 floats for seq <= 96) and every f16 MFMA attention need them
   L.lse = o;   o += al4(t->weight_format == 2 ? (M / t->seq) * t->seq * (size_t)t->heads
@@ -80,9 +88,6 @@ static int check_tower(const clipfs_tower* t, int batch) {
   return CLIPFS_OK;
 }
 
-// fp16 storage mode runs attention on the f16 MFMA kernels (attention_f16.hip; sequences up to 288 tokens)
-static inline bool f16_attention(const clipfs_tower* t) { return t->weight_format == 2 && t->seq <= 288; }
-
 static thread_local float* g_ws = nullptr;  // split-K scratch of the tower call in progress (its scratch buffer)
 static thread_local size_t g_ws_floats = 0;
 static thread_local int g_b_format = 0;  // format of the blocks' 16-bit weight copies for the call in progress
@@ -96,7 +101,8 @@ enum GemmChain { CHAIN_NONE = 0, CHAIN_OUT16 = 1, CHAIN_IN16 = 2 };
 // a16_ready: f16 image of A written by the producing kernel (LayerNorm / attention); NULL = convert here.
 static int gemm(const float* A, const float* B, const void* Bp, float* C, int M, int N, int K, const float* bias,
                 const float* res, int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r,
-                int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE, const void* a16_ready = nullptr) {
+                int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE, const void* a16_ready = nullptr,
+                void* c16_only = nullptr) {
   clipfs_gemm_args a = {};
   a.B_planes = Bp;
   a.b_format = g_b_format;
@@ -121,6 +127,12 @@ static int gemm(const float* A, const float* B, const void* Bp, float* C, int M,
       a.C = nullptr;
     }
     a.aux_f16 = 1;  // fp16 storage of the saved pre-activation (only the f16 x f16 GEMMs read or write it)
+    if (c16_only) {  // the result is kept as f16 alone (qkv in fp16 storage)
+      a.C_f16 = c16_only;
+      a.C = nullptr;
+    }
+  } else {
+    CLIPFS_REQUIRE(!c16_only, "tower: the f16 x f16 GEMM is required for an f16-only result");
   }
   return clipfs_gemm_nt(&a, st);
 }
@@ -184,11 +196,13 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
                                         train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
     if (qkv_mask)
       CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, st));
+    const bool q16 = qkv_f16(t);
     CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
-                      b.lora_b_qkv, r, 3, d, t->lora_scale, st, CHAIN_NONE, h16));
+                      b.lora_b_qkv, r, 3, d, t->lora_scale, st, CHAIN_NONE, h16, q16 ? (void*)qkv : nullptr));
     const void* att16 = nullptr;
     if (f16_attention(t)) {
-      CLIPFS_CHECK(clipfs_attention_f16_fwd(qkv, att, h16, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
+      CLIPFS_CHECK(clipfs_attention_f16_fwd(qkv, q16, att, h16, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads,
+                                            t->causal, st));
       att16 = h16;
     } else
       CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
@@ -265,8 +279,8 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
     const void* dqkv16_ready = nullptr;
     if (f16_attention(t)) {
-      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dqkv16, dh, batch, t->seq,
-                                            t->heads, t->causal, st));
+      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dqkv, dqkv16, dh, batch,
+                                            t->seq, t->heads, t->causal, st));
       dqkv16_ready = dqkv16;
     } else
       CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,

@@ -471,6 +471,9 @@ def test_attention_f16_fwd(batch, seq, heads, causal):
     ro, rl = _attn_ref64(qkv, batch, seq, heads, causal)
     assert (out.double() - ro).abs().max().item() < 2e-3
     assert (lse.double() - rl).abs().max().item() < 1e-3
+    # fp16 storage of qkv: the same values read as an f16 tensor give the same bits (the staging conversion is exact here)
+    out_h, lse_h = ops.attention_f16_fwd(qkv.half(), batch, seq, heads, causal)
+    assert torch.equal(out_h, out) and torch.equal(lse_h, lse)
 
 
 @pytest.mark.gpu
@@ -486,6 +489,7 @@ def test_attention_f16_bwd(batch, seq, heads, causal):
     dout = torch.randn(batch * seq, heads * 64, generator=g).half().float().cuda()
     out, lse = ops.attention_f16_fwd(qkv, batch, seq, heads, causal)
     dqkv = ops.attention_f16_bwd(qkv, dout, out, lse, batch, seq, heads, causal)
+    assert torch.equal(ops.attention_f16_bwd(qkv.half(), dout, out, lse, batch, seq, heads, causal), dqkv)
     x = qkv.double().requires_grad_(True)
     ro, _ = _attn_ref64(x, batch, seq, heads, causal)
     (ro * dout.double()).sum().backward()
