@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD, speed only),
   // each XCD has a private 4 MB L2: give every XCD a CONTIGUOUS run of the tile list, and order the list in
   // super-tiles of GM m-blocks x all n-blocks (m fastest) so the ~96 tiles an XCD runs at once share
-  // 16 A panels and 6 B panels instead of ~40 + 18 (FETCH_SIZE: DESIGN.md section 8).
+  // 8 A panels and 12 B panels instead of ~40 + 18 (FETCH_SIZE: DESIGN.md section 8; GM = 8 fetches 10-25 % less than
+  // 16 on four of the five path shapes, 4 and 32 more; the time does not move: the kernel is MFMA-bound).
   int tile;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   }
   const int split = tile % p.splits;  // consecutive units = the K slices of one tile (same XCD: shared panels)
   tile /= p.splits;
-  constexpr int GM = 16;
+  const int GM = p.gm;
   const int nbn = p.n_blocks_n;
   const int grp = tile / (GM * nbn);
   const int rem = tile - grp * (GM * nbn);
@@ -437,6 +438,8 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   static const int ablate_cfg = getenv("CLIPFS_GEMM_ABLATE") ? atoi(getenv("CLIPFS_GEMM_ABLATE")) : 0;
   p.ablate = ablate_cfg;
   p.grid_g = 0;
+  static const int gm_cfg = getenv("CLIPFS_GEMM_GM") ? atoi(getenv("CLIPFS_GEMM_GM")) : 8;  // tuning aid
+  p.gm = gm_cfg > 0 ? gm_cfg : 8;
   if (a.a_mode == 0) {
     CLIPFS_REQUIRE((a.lda & 3) == 0 && a.lda >= a.K && aligned16(a.A), "gemm: lda must be a multiple of 4 and >= K, A 16-byte aligned");
   } else {

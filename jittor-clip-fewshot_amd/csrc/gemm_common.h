@@ -13,6 +13,7 @@ struct GemmParams {
   int grid_g;      // a_mode 1: patches per side
   int splits;      // split-K factor (1 = none): unit u = tile * splits + split, split s covers K-steps [s*nk/S, (s+1)*nk/S)
   float* part;     // splits > 1: raw partial sums, slab s at part + s * M * N (row-major, ld = N)
+  int gm;          // super-tile height in m-blocks (tile order: gm m-blocks x all n-blocks, m fastest)
   int ablate;      // tuning aid (CLIPFS_GEMM_ABLATE): 1 no global prefetch, 2 no LDS store, 4 no barrier -- WRONG RESULTS
 };
 
