@@ -474,3 +474,72 @@ def test_fp16_precision_mode_l14(dev, monkeypatch):
     # LoRA / prompt gradients of the fp16 path (f16 GEMM operands, f16 MFMA attention fwd + bwd) against the exact
     # fp32 path: 3e-2 of the largest entry
     assert (g16 - g32).abs().max().item() < 3e-2 * g32.abs().max().item()
+
+
+def test_three_step_training_trajectory(dev, monkeypatch):
+    """Three consecutive LoRATrainer.step calls (LoRA dropout 0.25 with a fresh Philox seed per step, prompt ctx, AdamW
+    moments carried across steps) against the oracle run as a loop: per-step loss and the trainables after step 3."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    from clipfs.engine import _mix_seed
+    from oracle import clip_oracle as O
+    cfg = synth.SMALL
+    params, p = ("q", "k", "v"), 0.25
+    sd, model = _build(cfg, dev)
+    args = _args("small", params=params, r=4, p=p)
+    lw = synth.synth_lora(cfg, 4, seed=5, params=params)
+    layers = _apply(model, cfg, args, lw, monkeypatch)
+    L.mark_only_lora_as_trainable(model)
+    B, Cn = 6, 9
+    img = synth.synth_images(B, cfg.image_resolution, seed=3)
+    cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=4, max_len=12)
+    tgt = synth.synth_labels(B, Cn, seed=2)
+    ctx_param = torch.nn.Parameter(sd["token_embedding.weight"][[5, 6, 7, 8]].clone().to(dev))
+    model.train()
+    lr = 1e-2  # large enough that three steps move the parameters well above fp32 noise
+    tr = L.LoRATrainer(model, prompt_ctx=ctx_param, lr=lr)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    tl, vl = _oracle_lora(lw, cfg, requires_grad=True)
+    octx = ctx_param.detach().double().cpu().requires_grad_()
+    names = {"q": "q_proj", "k": "k_proj", "v": "v_proj"}
+    leaves = [t for blk in list(tl.values()) + list(vl.values()) for ab in blk.values() for t in ab.values()] + [octx]
+    mom = [(torch.zeros_like(t), torch.zeros_like(t)) for t in leaves]
+
+    def drops(seed, width, seq, n, layers_n, stream0):
+        out = {}
+        for l in range(layers_n):
+            d = {}
+            for s, pr in enumerate(("q", "k", "v")):
+                keep = O.dropout_keep_mask(seed, stream0 + 4 * l + s, n * seq, width, p)
+                d[names[pr]] = (torch.from_numpy(keep).double() / (1 - p)).reshape(n, seq, width).permute(1, 0, 2)
+            out[l] = d
+        return out
+
+    for step in range(1, 4):
+        loss_sum, _, _ = tr.step(img.to(dev), cap.to(dev), tgt.to(dev))
+        seed = _mix_seed(model.engine.seed_base, model.engine.step)
+        td = drops(seed, cfg.transformer_width, cfg.context_length, Cn, cfg.transformer_layers, 0)
+        vd = drops(seed, cfg.vision_width, cfg.vision_tokens, B, cfg.vision_layers, 1000)
+        for t in leaves:
+            t.grad = None
+        loss, _ = O.train_step_loss(sd64, img.double(), cap, tgt, tl, vl, O.lora_scaling(1, 4), text_drops=td,
+                                    vis_drops=vd, ctx=octx, text_chunk=Cn)
+        loss.backward()
+        assert abs(loss_sum.item() / B - loss.item()) < 2e-4, (step, loss_sum.item() / B, loss.item())
+        with torch.no_grad():
+            for i, t in enumerate(leaves):
+                new, m, v = O.jt_adamw_step(t.detach(), t.grad, mom[i][0], mom[i][1], step, lr=lr)
+                t.copy_(new)
+                mom[i] = (m, v)
+    # trainables after three steps, layer by layer in apply_lora order, then the prompt ctx
+    blocks = list(tl.values()) + list(vl.values())
+    worst, moved = 0.0, 0.0
+    for i, layer in enumerate(layers):
+        for pr in params:
+            m = getattr(layer, names[pr])
+            for nm, prm in (("w_lora_A", m.w_lora_A), ("w_lora_B", m.w_lora_B)):
+                want = blocks[i][names[pr]][nm].detach()
+                worst = max(worst, _err(prm, want))
+                moved = max(moved, (want - torch.from_numpy(lw[f"layer_{i}"][names[pr]][nm]).double()).abs().max().item())
+    worst = max(worst, _err(ctx_param, octx))
+    assert moved > 1e-2 and worst < 2e-4, (moved, worst)
