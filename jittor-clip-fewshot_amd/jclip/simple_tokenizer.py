@@ -9,9 +9,8 @@ Differences from the reference, both deliberate:
   * the vocabulary file: the reference looks for ``bpe_simple_vocab_16e6.txt.gz``
     (``simple_tokenizer.py:12-13``) while the file it ships is named
     ``bpe_simple_vocab_16e6.txt`` but holds gzip bytes.  ``default_bpe()`` resolves, in
-    order, ``$CLIPFS_BPE_PATH``, either name next to this module, then either
-    name under ``/root/reference/jclip`` (build container only); gzip is detected
-    from the magic bytes, not the suffix.
+    order, ``$CLIPFS_BPE_PATH``, then either name next to this module (the vocabulary
+    ships in-tree); gzip is detected from the magic bytes, not the suffix.
   * ``ftfy.fix_text`` (``simple_tokenizer.py:55``) is applied when ``ftfy`` is
     importable and skipped otherwise (identity on the ASCII class names and
     templates this task uses).
@@ -48,7 +47,6 @@ def default_bpe() -> str:
     names = ("bpe_simple_vocab_16e6.txt.gz", "bpe_simple_vocab_16e6.txt")
     cands = [os.environ.get("CLIPFS_BPE_PATH", "")]
     cands += [os.path.join(here, n) for n in names]
-    cands += [os.path.join("/root/reference/jclip", n) for n in names]
     for c in cands:
         if c and os.path.isfile(c):
             return c
