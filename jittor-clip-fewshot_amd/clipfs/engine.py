@@ -116,7 +116,9 @@ class _TowerRT:
         t.width, t.heads, t.layers, t.seq, t.causal = (self.width, self.heads, self.layers, seq or self.seq,
                                                        int(self.causal))
         t.lora_r, t.lora_scale, t.lora_dropout = r, scale, p
-        t.dropout_seed = seed if (train and p > 0) else 0
+        # dropout follows the MODULE's train mode (LinearLoRA.execute, lora_train_vlp.py:297-298), not whether
+        # activations are saved: a no-grad forward in train mode (slow_pace.py:1659-1661) still drops
+        t.dropout_seed = seed if p > 0 else 0
         t.dropout_stream0 = self.stream0
         t.weight_format = {"fp32": 0, "bf16x3": 1, "fp16": 2}[self.precision]
         t.blocks = C.cast(blocks, C.POINTER(Block))
@@ -139,11 +141,20 @@ class _TowerRT:
             self._bufs[key] = buf
         return buf
 
-    def forward(self, x: torch.Tensor, batch: int, train: bool, seed: int, seq: Optional[int] = None):
+    def forward(self, x: torch.Tensor, batch: int, train: bool, seed: int, seq: Optional[int] = None,
+                own_saved: bool = False):
+        """``train`` = keep the activations the backward needs.  ``own_saved``: give this call its OWN saved-activation
+        tensor (the autograd route: several grad-enabled forwards of one tower may precede one backward, e.g. the 13
+        caption chunks of encode_text_in_batches, lora_train_vlp.py:905-912); otherwise the per-tower cached buffer
+        is reused (LoRATrainer: exactly one forward per backward)."""
         lib = _lib.load()
         t = self.descriptor(train, seed, seq)
         scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), x.device)
-        saved = self.buffer("saved", lib.clipfs_tower_saved_floats(C.byref(t), batch), x.device) if train else None
+        saved = None
+        if train:
+            n = lib.clipfs_tower_saved_floats(C.byref(t), batch)
+            saved = torch.empty(max(n, 4), device=x.device, dtype=torch.float32) if own_saved else \
+                self.buffer("saved", n, x.device)
         check(lib.clipfs_tower_fwd(C.byref(t), x.data_ptr(), batch, _ptr(saved), scratch.data_ptr(),
                                    torch.cuda.current_stream().cuda_stream), "tower_fwd")
         return saved
@@ -195,7 +206,7 @@ class Engine:
         return _mix_seed(self.seed_base, self.step)
 
     # -- image tower --------------------------------------------------------------------------------
-    def vit_forward(self, images: torch.Tensor, train: bool, seed: int = 0):
+    def vit_forward(self, images: torch.Tensor, train: bool, seed: int = 0, own_saved: bool = False):
         m = self.model
         v = m.visual
         assert images.is_cuda and images.dtype == torch.float32, "images: fp32 device tensor [B,3,R,R]"
@@ -215,7 +226,7 @@ class Engine:
         else:
             x = ops.layernorm_fwd(x0, v.ln_pre.weight.data, v.ln_pre.bias.data)
             mean0 = rstd0 = None
-        saved = self.vis.forward(x, B, train, seed)
+        saved = self.vis.forward(x, B, train, seed, own_saved=own_saved)
         if train:
             y, mean1, rstd1 = ops.layernorm_fwd(x, v.ln_post.weight.data, v.ln_post.bias.data, ldx=L * d, rows=B,
                                                 save_stats=True)
@@ -258,7 +269,8 @@ class Engine:
             self._trim_cache = {key: hit}
         return hit
 
-    def text_forward(self, ids: torch.Tensor, prompt_ctx: Optional[torch.Tensor], train: bool, seed: int = 0):
+    def text_forward(self, ids: torch.Tensor, prompt_ctx: Optional[torch.Tensor], train: bool, seed: int = 0,
+                     own_saved: bool = False):
         m = self.model
         ids = ids.to(device=m.device, dtype=torch.int64).contiguous()
         n, seq = ids.shape
@@ -267,7 +279,7 @@ class Engine:
         ids, seq = self._effective_ids(ids)
         x = ops.text_embed(ids, m.token_embedding.weight.data, m.positional_embedding.data,
                            None if prompt_ctx is None else prompt_ctx.data)
-        saved = self.txt.forward(x, n, train, seed, seq)
+        saved = self.txt.forward(x, n, train, seed, seq, own_saved=own_saved)
         rows, idx = ops.gather_eot(x, ids)
         if train:
             y, mean, rstd = ops.layernorm_fwd(rows, m.ln_final.weight.data, m.ln_final.bias.data, save_stats=True)
@@ -319,7 +331,7 @@ class _EncodeImage(torch.autograd.Function):
         eng = model.engine
         train = model.training
         seed = eng.next_seed() if train else 0
-        feat, c = eng.vit_forward(images, True, seed)
+        feat, c = eng.vit_forward(images, True, seed, own_saved=True)
         ctx.model, ctx.c = model, c
         return feat
 
@@ -343,7 +355,7 @@ class _EncodeText(torch.autograd.Function):
     def forward(ctx, model, ids, prompt_ctx, *params):
         eng = model.engine
         seed = eng.next_seed() if model.training else 0
-        feat, c = eng.text_forward(ids, prompt_ctx, True, seed)
+        feat, c = eng.text_forward(ids, prompt_ctx, True, seed, own_saved=True)
         ctx.model, ctx.c, ctx.prompt = model, c, prompt_ctx
         return feat
 
@@ -368,7 +380,9 @@ def encode_image(model, images: torch.Tensor) -> torch.Tensor:
         params.append(model.visual.VPT)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return _EncodeImage.apply(model, images, *params)
-    feat, _ = model.engine.vit_forward(images, False)
+    # no-grad route: dropout still follows model.training (reference: a second encode_image under jt.no_grad() in
+    # train mode, slow_pace.py:1612,1659-1661, is dropout-on)
+    feat, _ = model.engine.vit_forward(images, False, model.engine.next_seed() if model.training else 0)
     return feat
 
 
@@ -378,7 +392,7 @@ def encode_text(model, ids: torch.Tensor, prompt_ctx: Optional[torch.Tensor] = N
     needs = any(p.requires_grad for p in params) or (prompt_ctx is not None and prompt_ctx.requires_grad)
     if torch.is_grad_enabled() and needs:
         return _EncodeText.apply(model, ids, prompt_ctx, *params)
-    feat, _ = model.engine.text_forward(ids, prompt_ctx, False)
+    feat, _ = model.engine.text_forward(ids, prompt_ctx, False, model.engine.next_seed() if model.training else 0)
     return feat
 
 

@@ -164,7 +164,9 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
   g_b_format = t->weight_format;
   g_a16 = t->weight_format == 2 ? scratch + SC.a16 : nullptr;
   g_c16 = t->weight_format == 2 ? scratch + SC.c16 : nullptr;
-  const uint64_t seed = train ? t->dropout_seed : 0;  // dropout only when training (is_training(), :298)
+  // dropout follows the caller's train MODE (is_training(), lora_train_vlp.py:297-298), carried by a non-zero seed;
+  // `saved` only decides whether activations are kept (a no-grad forward in train mode still drops)
+  const uint64_t seed = t->dropout_seed;
   if (train) {
     hipError_t e = hipMemcpyAsync(saved + SL.x_in, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, st);
     CLIPFS_REQUIRE(e == hipSuccess, "tower_fwd: memcpy failed: %s", hipGetErrorString(e));

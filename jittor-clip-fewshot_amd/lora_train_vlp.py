@@ -353,10 +353,11 @@ def cls_acc(output, target, topk=1):
     return 100.0 * float(correct.float().sum().item()) / target.shape[0]
 
 
-@torch.no_grad()
 def encode_text_in_batches(clip_model, texts, batch_size=32):
-    """:907-919.  Captions are independent rows, so the engine encodes them in one pass; ``batch_size``
-    is accepted for signature compatibility."""
+    """:907-919 -- the DIFFERENTIABLE text path of the training loop (called at :975 under
+    ``clip_model.train()``; the text-tower LoRA is trained through it), so no ``no_grad`` here:
+    ``encode_text`` decides by ``requires_grad``.  Captions are independent rows, so the engine encodes
+    them in one pass; ``batch_size`` is accepted for signature compatibility."""
     if len(texts) == 0:
         raise ValueError("No embeddings were generated. Please check your batch processing.")
     return clip_model.encode_text(clip.tokenize(list(texts)))

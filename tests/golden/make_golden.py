@@ -73,6 +73,64 @@ def block_case():
                         dy=dy.numpy().astype(np.float32), y=y.detach().numpy(), dx=x.grad.numpy())
 
 
+FULL_B, FULL_C, FULL_P = 8, 16, 0.25
+FULL_PROMPT_IDS = [320, 1125, 539, 320]  # "a photo of a" (slow_pace.py:124-131)
+
+
+def full_case():
+    """cfg-2 at FULL DEPTH: ViT-B/32 (12 + 12 blocks, synth seed 1234), the shipped lora_weights.pkl (r=4, q/k/v),
+    4 prompt tokens, Philox dropout 0.25 with the engine's first-step seed, B = 8 images / C = 16 captions, one
+    run_lora step (lora_train_vlp.py:956-1002) in fp64: loss, logits, top-5 and the flat LoRA + prompt gradient in
+    FlatTrainables order (text blocks then vision blocks, per block A_qkv [3r, d] then B_qkv [3d, r]; then ctx)."""
+    from clipfs.engine import _mix_seed
+    cfg = synth.VIT_B32
+    sd = {k: v.double() for k, v in synth.synth_state_dict(cfg, seed=1234).items()}
+    ck = safe_pkl.load(os.path.join(HERE, "lora_weights.pkl"))
+    tl, vl = O.split_lora_checkpoint(ck["weights"], "both", "all", "ViT-B/32")
+    blocks = list(tl.values()) + list(vl.values())
+    for blk in blocks:
+        for ab in blk.values():
+            for t in ab.values():
+                t.requires_grad_()
+    B, Cn, p = FULL_B, FULL_C, FULL_P
+    img = synth.synth_images(B, 224, seed=0).double()
+    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=1)
+    tgt = synth.synth_labels(B, Cn, seed=2)
+    ctx = sd["token_embedding.weight"][FULL_PROMPT_IDS].clone().requires_grad_()
+    seed = _mix_seed(0x5EED, 1)  # Engine.seed_base, first step
+
+    def drops(width, seq, n, layers_n, stream0):
+        out = {}
+        for l in range(layers_n):
+            d = {}
+            for s, name in enumerate(("q_proj", "k_proj", "v_proj")):
+                keep = O.dropout_keep_mask(seed, stream0 + 4 * l + s, n * seq, width, p)
+                d[name] = (torch.from_numpy(keep).double() / (1 - p)).reshape(n, seq, width).permute(1, 0, 2)
+            out[l] = d
+        return out
+
+    td = drops(cfg.transformer_width, 77, Cn, 12, 0)
+    vd = drops(cfg.vision_width, 50, B, 12, 1000)
+    loss, logits = O.train_step_loss(sd, img, cap, tgt, tl, vl, O.lora_scaling(1, 4), text_drops=td, vis_drops=vd,
+                                     ctx=ctx, text_chunk=Cn)
+    loss.backward()
+    flat = []
+    for blk in blocks:
+        flat.append(torch.cat([blk[n]["w_lora_A"].grad for n in ("q_proj", "k_proj", "v_proj")], 0).reshape(-1))
+        flat.append(torch.cat([blk[n]["w_lora_B"].grad for n in ("q_proj", "k_proj", "v_proj")], 0).reshape(-1))
+    flat.append(ctx.grad.reshape(-1))
+    flat = torch.cat(flat)
+    with torch.no_grad():  # eval-mode (no dropout) logits of the same inputs: the bench's top-5 check uses these
+        fi = O.l2_normalize(O.encode_image(sd, img, vl, O.lora_scaling(1, 4)))
+        pe = O.build_prompts(ctx.detach(), sd["token_embedding.weight"], cap)
+        ft = O.l2_normalize(O.encode_text(sd, cap, tl, O.lora_scaling(1, 4), embeds=pe))
+        ev = 100.0 * fi @ ft.t()
+    np.savez_compressed(os.path.join(HERE, "vitb32_full_step.npz"), loss=np.array(loss.item()),
+                        logits=logits.detach().numpy(), top5=O.jt_topk(logits.detach().float(), 5).numpy(),
+                        flat_grad=flat.numpy().astype(np.float32), grad_max=np.array(flat.abs().max().item()),
+                        eval_logits=ev.numpy(), eval_top5=O.jt_topk(ev.float(), 5).numpy(), seed=np.array(seed, dtype=np.uint64))
+
+
 def mta_case():
     g = torch.Generator().manual_seed(41)
     V, d, Cn = 65, 512, 403
@@ -105,6 +163,8 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     tiny_case()
     block_case()
+    if "--no-full" not in sys.argv:
+        full_case()
     mta_case()
     tokenizer_case()
     philox_case()

@@ -99,6 +99,57 @@ def test_vitb32_block_vs_golden(dev, golden_dir):
     assert np.abs(dx - z["dx"]).max() < 1e-4
 
 
+def build_cfg2(dev, golden_dir, dropout):
+    """Full ViT-B/32 (synth seed 1234) + the shipped LoRA checkpoint + 4 prompt tokens: the bench's cfg-2 model."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    from jclip.model import build_model
+    model = build_model(synth.synth_state_dict(synth.VIT_B32, seed=1234), device=dev)
+    args = types.SimpleNamespace(encoder="both", position="all", backbone="ViT-B/32", params=["q", "k", "v"], r=4,
+                                 alpha=1, dropout_rate=dropout)
+    layers = L.apply_lora(args, model)
+    L.load_lora(args, layers, os.path.join(golden_dir, "lora_weights.pkl"))
+    L.mark_only_lora_as_trainable(model)
+    ctx = torch.nn.Parameter(model.token_embedding.weight.data[torch.tensor([320, 1125, 539, 320], device=dev)].clone())
+    return model, ctx
+
+
+def test_vitb32_full_step_vs_golden(dev, golden_dir):
+    """cfg-2 at FULL DEPTH (12 + 12 blocks, shipped LoRA, prompt tokens, Philox dropout 0.25): loss, logits, top-5
+    and the whole flat LoRA + prompt gradient of one run_lora step (lora_train_vlp.py:956-1002) against the fp64
+    golden -- the 12-block error accumulation of the backward, which the small-model tests cannot show."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    z = np.load(os.path.join(golden_dir, "vitb32_full_step.npz"))
+    model, ctx = build_cfg2(dev, golden_dir, 0.25)
+    B, Cn = z["logits"].shape
+    img = synth.synth_images(B, 224, seed=0).to(dev)
+    cap = synth.synth_captions(Cn, 77, synth.VIT_B32.vocab_size, seed=1).to(dev)
+    tgt = synth.synth_labels(B, Cn, seed=2).to(dev)
+    model.eval()
+    tr = L.LoRATrainer(model, prompt_ctx=ctx)
+    with torch.no_grad():
+        fi = L.ops.l2norm_fwd(model.encode_image(img))
+        ft = L.ops.l2norm_fwd(model.encode_text(cap, ctx))
+        ev = L.ops.gemm_nt(fi, ft, alpha=100.0)
+    assert np.abs(ev.cpu().numpy() - z["eval_logits"]).max() < 1e-3
+    assert np.array_equal(L.ops.topk(ev, 5).cpu().numpy(), z["eval_top5"])
+    model.train()
+    assert model.engine.step == 0  # the golden's dropout seed is the engine's first-step seed
+    tr.flat.zero_grad()
+    loss_sum, _, logits = tr.forward_backward(img, cap, tgt)
+    from clipfs.engine import _mix_seed
+    assert _mix_seed(model.engine.seed_base, model.engine.step) == int(z["seed"])
+    err = np.abs(logits.cpu().numpy() - z["logits"]).max()
+    assert err < 1e-3, err                                            # north-star tolerance on 100 x cosine
+    assert abs(loss_sum.item() / B - float(z["loss"])) < 1e-4
+    assert np.array_equal(L.ops.topk(logits, 5).cpu().numpy(), z["top5"])  # top-5 labels bit-exact
+    g = tr.flat.grads.cpu().numpy()
+    assert g.shape == z["flat_grad"].shape
+    gerr = np.abs(g - z["flat_grad"]).max()
+    assert gerr <= 1e-4 * float(z["grad_max"]), (gerr, float(z["grad_max"]))
+
+
 def test_mta_vs_golden(dev, golden_dir):
     from clipfs import ops
     import ood

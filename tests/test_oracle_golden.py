@@ -122,3 +122,25 @@ def test_logit_normalize_and_std_clamp():
     assert torch.allclose(n.mean(dim=1), torch.zeros(6, dtype=torch.float64), atol=1e-12)
     assert torch.allclose(O.jt_std(z), z.flatten().std(unbiased=True))
     assert O.jt_std(torch.ones(3, 3)).item() == pytest.approx(1e-3)  # sqrt(clamp(0, 1e-6))
+
+
+def test_full_depth_fixture_eval_logits(golden_dir):
+    """vitb32_full_step.npz: the dropout-free logits / top-5 of the full-depth cfg-2 model are recomputed here (the
+    train-step part of the fixture takes the oracle ~20 s in fp64 and is regenerated by make_golden.py only)."""
+    z = np.load(os.path.join(golden_dir, "vitb32_full_step.npz"))
+    cfg = synth.VIT_B32
+    sd = {k: v.double() for k, v in synth.synth_state_dict(cfg, seed=1234).items()}
+    ck = safe_pkl.load(os.path.join(golden_dir, "lora_weights.pkl"))
+    tl, vl = O.split_lora_checkpoint(ck["weights"], "both", "all", "ViT-B/32")
+    B, Cn = z["eval_logits"].shape
+    img = synth.synth_images(B, 224, seed=0).double()
+    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=1)
+    ctx = sd["token_embedding.weight"][[320, 1125, 539, 320]]
+    with torch.no_grad():
+        fi = O.l2_normalize(O.encode_image(sd, img, vl, 0.5))
+        ft = O.l2_normalize(O.encode_text(sd, cap, tl, 0.5, embeds=O.build_prompts(ctx, sd["token_embedding.weight"], cap)))
+        ev = 100.0 * fi @ ft.t()
+    assert np.allclose(ev.numpy(), z["eval_logits"], atol=1e-9)
+    assert np.array_equal(O.jt_topk(ev.float(), 5).numpy(), z["eval_top5"])
+    # 12 text + 12 vision blocks x (A_qkv [3r, d] + B_qkv [3d, r]) at r = 4, plus the 4 x 512 prompt tokens
+    assert z["flat_grad"].size == 12 * 2 * 3 * 4 * 512 + 12 * 2 * 3 * 4 * 768 + 4 * 512
