@@ -2,7 +2,10 @@
 """Headline benchmark (BASELINE.json): images/sec of the ViT-B/32 forward + LoRA backward train step.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 either way: under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or from a bare shell -- then this
+    process, BEFORE it makes any GPU call, starts that same launcher as a child, relays rank 0's JSON line and
+    exits with the child's status.
 
 Workload (config.workload): cfg-2 of BASELINE.json -- ViT-B/32, rank-4 LoRA on q,k,v of all 12+12
 blocks (weights = the reference's shipped lora_weights.pkl), 4 learnable text-prompt tokens, one
@@ -12,13 +15,16 @@ Synthetic data (N(0,1) images, random captions, CLIP-init random backbone: no ne
 in HBM before the timed region.  One step = one such pass over one global batch of 256 images.
 
 N > 1 is STRONG scaling (global batch fixed at 256, 256/N images per rank); the
-text tower is class-sharded (403/N captions per rank), collectives: all-gather + reduce of the
-[403,512] class features and ONE all-reduce of the flat 1.5 MB LoRA+prompt gradient buffer.
-``--weak`` keeps 256 images per rank instead.
+text tower is class-sharded (ceil(403/N) captions per rank); collectives per step over RCCL: ONE
+all_gather_into_tensor of the class-feature blocks, ONE reduce_scatter_tensor of their gradient and ONE all-reduce
+of the flat 1.5 MB LoRA+prompt gradient buffer (clipfs/dist.py); their per-step time is measured with HIP events
+and reported (``collective_ms_per_step``).  ``--weak`` keeps 256 images per rank instead.
 
 Rank 0 prints ONE JSON line.  Extra objects: ``roofline`` (dominant kernel = the fp32-MFMA GEMM; every
 GEMM launch of one extra, instrumented step is bracketed by HIP events on its launch stream) and
-``cpu_baseline`` (the CPU oracle timed on the host cores on a bounded sample; N = 1 only).
+``cpu_baseline`` (the CPU oracle timed on the host cores on a bounded sample; N = 1 only), ``top5_match`` (top-5
+labels of the full-depth model on the committed golden inputs, tests/golden/vitb32_full_step.npz), ``forward_only``
+(the north-star's own target: image-tower forward at bs 256) and ``cfg5`` (a short ViT-L/14 fp16-mode leg).
 In the timed region the text tower runs on a side HIP stream next to the image tower (they are independent
 until the logits); the instrumented roofline step serialises them so each GEMM's duration is its own.
 """
@@ -28,6 +34,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -64,16 +72,49 @@ def parse():
                     help="opt-in: skip the text positions after the batch's last EOT (dead under the causal mask); "
                          "NOT the headline configuration")
     ap.add_argument("--forward-only", action="store_true", help="time the zero-grad image forward only (diagnostic)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / cfg5 legs after the timed region")
+    ap.add_argument("--cfg5-budget-s", type=float, default=150.0,
+                    help="skip the cfg-5 leg when the run has already taken this many seconds")
     return ap.parse_args()
 
 
-def build_trainer(dev, args, world):
+def self_launch(args) -> int:
+    """``--gpus N`` from a bare shell: start the N ranks as a CHILD (torch.distributed.run), relay rank 0's JSON line.
+    This process has made no GPU call (torch is not even imported yet), so nothing is re-exec'ed after GPU init."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        print(f"[bench] the {args.gpus}-rank child failed (rc={rc}, json={'yes' if line else 'no'})", file=sys.stderr, flush=True)
+        return rc or 1
+    print(line, flush=True)
+    return 0
+
+
+def build_trainer(dev, args, model_name=None, precision=None):
     import types
     import torch
     import lora_train_vlp as L
     from clipfs import synth
     from jclip.model import build_model
-    l14 = args.model == "l14"
+    model_name = model_name or args.model
+    l14 = model_name == "l14"
     cfg = synth.VIT_L14 if l14 else synth.VIT_B32
     sd = synth.synth_state_dict(cfg, seed=1234)
     model = build_model(sd, device=dev)
@@ -100,8 +141,35 @@ def build_trainer(dev, args, world):
     tr = L.LoRATrainer(model, prompt_ctx=ctx, shard_text=not args.no_shard_text)
     tr.overlap_towers = not args.serial_towers
     model.engine.trim_text = args.trim_text
-    model.engine.precision = args.precision
+    model.engine.precision = precision or args.precision
     return model, tr, cfg
+
+
+def golden_top5(model, tr, dev):
+    """Top-5 labels of the (dropout-free) cfg-2 model on the committed golden inputs (8 images x 16 captions,
+    tests/golden/vitb32_full_step.npz, written by the fp64 oracle): the metric's "top-5 match vs ref".  Must run before
+    the first optimiser step (the golden holds the pristine shipped adapters)."""
+    import numpy as np
+    import torch
+    from clipfs import ops, synth
+    path = os.path.join(ROOT, "tests", "golden", "vitb32_full_step.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    B, Cn = z["eval_logits"].shape
+    img = synth.synth_images(B, 224, seed=0).to(dev)
+    cap = synth.synth_captions(Cn, 77, synth.VIT_B32.vocab_size, seed=1).to(dev)
+    model.eval()
+    with torch.no_grad():
+        fi = ops.l2norm_fwd(model.encode_image(img))
+        ft = ops.l2norm_fwd(model.encode_text(cap, tr.prompt_ctx))
+        logits = ops.gemm_nt(fi, ft, alpha=100.0)
+        top5 = ops.topk(logits, 5).cpu().numpy()
+    model.train()
+    err = float(np.abs(logits.cpu().numpy() - z["eval_logits"]).max())
+    return {"top5_match": bool(np.array_equal(top5, z["eval_top5"])), "max_abs_logit_err": round(err, 7),
+            "tolerance": 1e-3, "golden": "tests/golden/vitb32_full_step.npz (fp64 oracle; 8 images x 16 captions, full-depth "
+                                        "ViT-B/32 + shipped LoRA + prompt tokens)"}
 
 
 def host_cores() -> int:
@@ -113,9 +181,21 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(steps=2):
-    """The CPU oracle (oracle/clip_oracle.py, fp32) on a bounded sample of the same workload: 16 images +
-    25 captions (the 256:403 ratio), forward + LoRA backward, all host cores."""
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(full_step_budget_s=45.0):
+    """The CPU oracle (oracle/clip_oracle.py, fp32 PyTorch-CPU restatement) on the host cores:
+    B = 8 images + 13 captions (the 256:403 ratio), forward and forward + LoRA backward, 2 warm-up + 5 timed
+    iterations each, median; then ONE full cfg-2 step (256 images + 403 captions) when the B = 8 time predicts it
+    fits the budget, else the B = 8 figure stands for it (the work is linear in B)."""
     import torch
     from clipfs import safe_pkl, synth
     from oracle import clip_oracle as O
@@ -125,44 +205,81 @@ def cpu_baseline(steps=2):
     sd = synth.synth_state_dict(cfg, seed=1234)
     ck = safe_pkl.load(os.path.join(ROOT, "tests", "golden", "lora_weights.pkl"))
     tl, vl = O.split_lora_checkpoint(ck["weights"], "both", "all", "ViT-B/32", dtype=torch.float32)
-    for blk in list(tl.values()) + list(vl.values()):
-        for ab in blk.values():
-            for t in ab.values():
-                t.requires_grad_()
-    B, Cn = 8, 13
-    img = synth.synth_images(B, 224, seed=0)
-    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=1)
-    tgt = synth.synth_labels(B, Cn, seed=2)
-    ts = []
-    t_begin = time.time()
-    for i in range(steps + 1):
+    params = [t for blk in list(tl.values()) + list(vl.values()) for ab in blk.values() for t in ab.values()]
+    for t in params:
+        t.requires_grad_()
+
+    def run(B, Cn, backward):
+        img = synth.synth_images(B, 224, seed=0)
+        cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=1)
+        tgt = synth.synth_labels(B, Cn, seed=2)
         t0 = time.time()
-        loss, _ = O.train_step_loss(sd, img, cap, tgt, tl, vl, 0.5)
-        loss.backward()
-        ts.append(time.time() - t0)
-        print(f"[bench] cpu baseline step {i}: {ts[-1]:.2f} s", file=sys.stderr, flush=True)
-        if time.time() - t_begin > 60 and len(ts) >= 2:
-            break
-    rest = ts[1:] if len(ts) > 1 else ts
-    t = sorted(rest)[len(rest) // 2]
-    steps = len(rest)
-    return {"value": round(B / t, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 (PyTorch-CPU restatement, NOT Jittor: Jittor is not installable offline), "
-                      f"{B} images + {Cn} captions fwd+LoRA-bwd, median of {steps} steps after 1 warm-up"}
+        if backward:
+            for t in params:
+                t.grad = None
+            loss, _ = O.train_step_loss(sd, img, cap, tgt, tl, vl, 0.5)
+            loss.backward()
+        else:
+            with torch.no_grad():
+                O.train_step_loss(sd, img, cap, tgt, tl, vl, 0.5)
+        return time.time() - t0
+
+    def median(B, Cn, backward, warm=2, timed=5):
+        ts = [run(B, Cn, backward) for _ in range(warm + timed)][warm:]
+        return sorted(ts)[len(ts) // 2]
+
+    B, Cn = 8, 13
+    t_fwd = median(B, Cn, False)
+    t_step = median(B, Cn, True)
+    print(f"[bench] cpu baseline B=8: fwd {t_fwd:.2f} s, fwd+bwd {t_step:.2f} s", file=sys.stderr, flush=True)
+    out = {"value": round(B / t_step, 3), "unit": "images/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+           "forward_images_per_s": round(B / t_fwd, 3),
+           "sample": f"oracle fp32 (PyTorch-CPU restatement, NOT Jittor: Jittor is not installable offline), "
+                     f"{B} images + {Cn} captions, forward and forward+LoRA-backward, median of 5 after 2 warm-ups"}
+    predicted = t_step * 256 / B
+    if predicted <= full_step_budget_s:
+        t_full = run(256, 403, True)
+        out["b256_step"] = {"images_per_s": round(256 / t_full, 3), "seconds": round(t_full, 2),
+                            "sample": "ONE full cfg-2 step on the CPU: 256 images + 403 captions forward+LoRA-backward"}
+        print(f"[bench] cpu baseline B=256 step: {t_full:.1f} s", file=sys.stderr, flush=True)
+    else:
+        out["b256_step"] = {"images_per_s": round(B / t_step, 3), "seconds": round(predicted, 1),
+                            "sample": "extrapolated from B = 8 (work is linear in the batch); not run: over the time budget"}
+    return out
+
+
+def gemm_traffic(lib, args):
+    """HBM-side traffic per launch of the dominant GEMM from the committed rocprofv3 --pmc passes (the counters cannot be
+    read from inside this process).  The file carries the source stamp of the GEMM it was measured on; a mismatch with the
+    loaded library means the figure is stale -> traffic is reported as null."""
+    if args.precision != "fp32" or args.model != "b32":
+        return None, "no PMC passes for this mode"
+    stamp = lib.clipfs_gemm_source_stamp().decode()
+    prof = os.path.join(ROOT, "profiles")
+    rounds = sorted(d for d in os.listdir(prof) if os.path.isfile(os.path.join(prof, d, "gemm_traffic.json"))) \
+        if os.path.isdir(prof) else []
+    for d in reversed(rounds):
+        with open(os.path.join(prof, d, "gemm_traffic.json")) as f:
+            j = json.load(f)
+        if j.get("gemm_source_stamp") == stamp:
+            return j.get("traffic_bytes_per_launch"), (
+                f"profiles/{d}/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, FETCH x2 "
+                f"per the gfx950 note; L2-side counters: Infinity-Cache hits included; measured on GEMM source {stamp})")
+    return None, f"no committed PMC pass matches the loaded GEMM (source stamp {stamp}): stale figures are not reported"
 
 
 def main():
     args = parse()
+    t_start = time.time()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP engine has no CPU fallback)")
     # CLIPFS_BENCH_REHEARSE=1: run the N-rank code path on a box with fewer GPUs than ranks (ranks share cards, gloo
@@ -180,7 +297,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from clipfs import _lib, dist as D, synth
-    model, tr, cfg = build_trainer(dev, args, world)
+    lib = _lib.load()
+    model, tr, cfg = build_trainer(dev, args)
+    top5 = golden_top5(model, tr, dev) if (args.model == "b32" and rank == 0) else None
     gb = args.batch * world if args.weak else args.batch
     lo, hi = D.shard_bounds(gb, rank, world)
     images = synth.synth_images(gb, 224, seed=0)[lo:hi].contiguous().to(dev)
@@ -194,7 +313,7 @@ def main():
                 model.engine.vit_forward(images, False)
             return
         tr.flat.zero_grad()
-        tr.forward_backward(images, captions, labels, 1, gb)
+        tr.forward_backward(images, captions, labels, 1, gb, row_offset=lo)
         tr.optimizer_step()
 
     def barrier():
@@ -220,10 +339,25 @@ def main():
     ms = dt / args.steps * 1e3
     value = gb * args.steps / dt
 
+    # ---- collectives: three more steps with every collective bracketed by HIP events on its launch stream ----
+    coll = None
+    if world > 1 and not args.forward_only:
+        tr.time_collectives = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        tr.time_collectives = False
+        times = tr.collective_times_ms()
+        per = {k: round(sum(v) / len(v), 4) for k, v in times.items()}
+        tot = torch.tensor([sum(per.values())], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+        coll = {"per_collective_ms": per, "total_ms_per_step_max_rank": round(tot.item(), 4),
+                "note": "HIP events around each collective on rank 0's launch stream (includes waiting for the slowest rank)"}
+    barrier()
+
     # ---- roofline leg: one more step with every GEMM launch bracketed by HIP events on its stream ----
     roof = None
     if not args.no_roofline:
-        lib = _lib.load()
         overlap = tr.overlap_towers
         tr.overlap_towers = False  # per-kernel durations are only meaningful when nothing else shares the GPU
         lib.clipfs_gemm_timing(1)
@@ -231,32 +365,7 @@ def main():
         torch.cuda.synchronize()
         lib.clipfs_gemm_timing(0)
         tr.overlap_towers = overlap
-        tms, tfl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        lib.clipfs_gemm_timing_collect(ctypes.byref(tms), ctypes.byref(tfl), ctypes.byref(n))
-        if n.value > 0 and tms.value > 0:
-            ach = tfl.value / (tms.value * 1e-3) / 1e12
-            # achieved counts ALGORITHMIC FLOPs (2MNK); the opt-in 16-bit modes are priced against the dense 16-bit
-            # MFMA peak divided by the products they spend per algorithmic multiply (3 for split-bf16, 1 for f16)
-            kname, peak = {
-                "fp32": ("gemm_nt_kernel<64,128,3> (v_mfma_f32_32x32x2_f32, global_load_lds staging)", FP32_MFMA_PEAK_TFLOPS),
-                "bf16x3": ("gemm_bf16x3_kernel<.,.,2> (3 x v_mfma_f32_32x32x16_bf16 per operand pair)", 2500.0 / 3),
-                "fp16": ("gemm_f16_kernel<256,128> (v_mfma_f32_32x32x16_f16, both operands f16 via global_load_lds)", 2500.0),
-            }[args.precision]
-            # HBM traffic per launch from the PMC counters cannot be collected from inside this process: it is the figure
-            # of the committed rocprofv3 --pmc passes over this same command (scripts/pmc_traffic.py), exact fp32 kernel only
-            traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01", "gemm_traffic.json")
-            if args.precision == "fp32" and args.model == "b32" and os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get("traffic_bytes_per_launch")
-                tsrc = "profiles/r01/gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per the gfx950 note; L2-side counters: Infinity-Cache hits included)"
-            roof = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": tsrc,
-                    "algorithmic_bytes_per_launch": round(lib.clipfs_gemm_timing_last_bytes() / n.value),
-                    "launches_per_step": n.value, "avg_launch_us": round(tms.value * 1e3 / n.value, 2),
-                    "gflop_per_launch": round(tfl.value / n.value / 1e9, 3),
-                    "gemm_ms_per_step": round(tms.value, 3)}
+        roof = collect_roofline(lib, args, args.precision)
     barrier()
 
     # ---- opt-in modes next to the headline (same step, same inputs; never the headline `value`) ----
@@ -281,6 +390,37 @@ def main():
             variants[name] = {"value": round(gb / vdt, 2), "unit": "images/s", "ms_per_step": round(vdt * 1e3, 3), "note": note}
         model.engine.trim_text, model.engine.precision = args.trim_text, args.precision
 
+    # ---- the north-star's own target: image-tower forward at bs 256 (>= 40 % of the MFMA roofline) ----
+    fwd_only = None
+    extras = world == 1 and not args.no_extras and not args.forward_only and args.model == "b32" and \
+        args.precision == "fp32" and not args.trim_text
+    if extras:
+        with torch.no_grad():
+            for _ in range(3):
+                model.engine.vit_forward(images, False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                model.engine.vit_forward(images, False)
+            torch.cuda.synchronize()
+        fdt = (time.perf_counter() - t1) / 10
+        ftf = gb * IMG_FWD / 1e3 / fdt
+        fwd_only = {"value": round(gb / fdt, 1), "unit": "images/s", "ms": round(fdt * 1e3, 3), "batch": gb,
+                    "tflops": round(ftf, 2), "frac_of_fp32_mfma_peak": round(ftf / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "workload": "ViT-B/32 image tower forward (eval, LoRA applied, no dropout), 10 passes after 3 warm-ups",
+                    "north_star_target": ">= 0.40 of the MFMA roofline"}
+
+    # ---- cfg-5 leg: ViT-L/14, rank-16 LoRA, fp16 storage mode, 128 images (one rank's share of bs 1024) + 403 captions ----
+    cfg5 = None
+    if extras:
+        if time.time() - t_start > args.cfg5_budget_s:
+            cfg5 = {"skipped": f"run already took {time.time() - t_start:.0f} s (budget {args.cfg5_budget_s:.0f} s)"}
+        else:
+            del images
+            model = tr = None
+            torch.cuda.empty_cache()
+            cfg5 = cfg5_leg(dev, args, lib)
+
     if rank == 0:
         n_img_local = hi - lo
         if args.model == "l14":  # 162.03 (+0.303 LoRA) per image, 13.30 per caption; dgrad ~= forward
@@ -289,6 +429,7 @@ def main():
             step_tflop = gb * IMG_FWD / 1e3
         else:
             step_tflop = (gb * (IMG_FWD + IMG_BWD) + args.classes * (TXT_FWD + TXT_BWD)) / 1e3
+        backend = D.backend_name()
         out = {
             "metric": "images/sec ViT-B/32 fwd+LoRA-bwd bs=256" if args.model == "b32" else
                       "images/sec ViT-L/14 fwd+LoRA-bwd (cfg-5 shapes)", "value": round(value, 2), "unit": "images/s",
@@ -304,16 +445,94 @@ def main():
             "algorithmic_tflop_per_step": round(step_tflop, 3),
             "step_tflops": round(step_tflop / (ms * 1e-3), 2),
             "step_frac_of_fp32_mfma_peak": round(step_tflop / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * world), 4),
+            "backend": backend,
+            "rccl_ranks": world if backend == "nccl" else 0,
+            "collectives_per_step": tr.collectives_per_step if tr is not None else 0,
         }
+        if rehearse:
+            out["rehearsal"] = "CLIPFS_BENCH_REHEARSE=1: ranks share GPUs over gloo -- a code-path rehearsal, NOT a measurement"
+        if coll:
+            out["collective_ms_per_step"] = coll
+        if top5:
+            out.update(top5_match=top5["top5_match"], top5=top5)
         if roof:
             out["roofline"] = roof
+        if fwd_only:
+            out["forward_only"] = fwd_only
+        if cfg5:
+            out["cfg5"] = cfg5
         if variants:
             out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def collect_roofline(lib, args, precision):
+    tms, tfl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    lib.clipfs_gemm_timing_collect(ctypes.byref(tms), ctypes.byref(tfl), ctypes.byref(n))
+    if n.value <= 0 or tms.value <= 0:
+        return None
+    ach = tfl.value / (tms.value * 1e-3) / 1e12
+    # achieved counts ALGORITHMIC FLOPs (2MNK); the opt-in 16-bit modes are priced against the dense 16-bit
+    # MFMA peak divided by the products they spend per algorithmic multiply (3 for split-bf16, 1 for f16)
+    kname, peak = {
+        "fp32": ("gemm_nt_kernel<64,128,3> (v_mfma_f32_32x32x2_f32, global_load_lds staging)", FP32_MFMA_PEAK_TFLOPS),
+        "bf16x3": ("gemm_bf16x3_kernel<.,.,2> (3 x v_mfma_f32_32x32x16_bf16 per operand pair)", 2500.0 / 3),
+        "fp16": ("gemm_f16_kernel (v_mfma_f32_32x32x16_f16, both operands f16 via global_load_lds)", 2500.0),
+    }[precision]
+    traffic, tsrc = gemm_traffic(lib, args) if precision == args.precision else (None, "not collected for this leg")
+    return {"bound": "mfma", "kernel": kname,
+            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": tsrc,
+            "algorithmic_bytes_per_launch": round(lib.clipfs_gemm_timing_last_bytes() / n.value),
+            "launches_per_step": n.value, "avg_launch_us": round(tms.value * 1e3 / n.value, 2),
+            "gflop_per_launch": round(tfl.value / n.value / 1e9, 3),
+            "gemm_ms_per_step": round(tms.value, 3)}
+
+
+def cfg5_leg(dev, args, lib):
+    """BASELINE.json configs[4] on one rank's share: ViT-L/14, rank-16 LoRA, fp16 storage mode (f16 x f16 MFMA GEMMs,
+    f16 MFMA attention, fp32 accumulate / residual stream), 128 images + 403 captions per step."""
+    import torch
+    from clipfs import synth
+    B = 128
+    t0 = time.time()
+    model, tr, cfg = build_trainer(dev, args, model_name="l14", precision="fp16")
+    images = synth.synth_images(B, 224, seed=0).to(dev)
+    labels = synth.synth_labels(B, 374, seed=2).to(dev)
+    captions = synth.synth_captions(403, 77, cfg.vocab_size, seed=1).to(dev)
+
+    def step():
+        tr.flat.zero_grad()
+        tr.forward_backward(images, captions, labels, 1, B)
+        tr.optimizer_step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n = 4
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / n
+    tr.overlap_towers = False
+    lib.clipfs_gemm_timing(1)
+    step()
+    torch.cuda.synchronize()
+    lib.clipfs_gemm_timing(0)
+    roof = collect_roofline(lib, args, "fp16")
+    step_tflop = (B * 2 * (162.03 + 0.303) + 403 * 2 * 13.30) / 1e3
+    print(f"[bench] cfg5 leg: {dt * 1e3:.1f} ms/step ({time.time() - t0:.0f} s incl. model build)", file=sys.stderr, flush=True)
+    return {"workload": "cfg-5 shapes on ONE GPU: ViT-L/14 + rank-16 LoRA (synthetic adapters), fp16 storage mode, 128 images "
+                        "(one rank's share of bs 1024) + 403 captions, train step; 4 steps after 2 warm-ups",
+            "value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2),
+            "step_tflops": round(step_tflop / dt, 1), "step_frac_of_f16_mfma_peak": round(step_tflop / dt / 2500.0, 4),
+            "gemm": roof}
 
 
 if __name__ == "__main__":

@@ -35,6 +35,10 @@ extern "C" {
 
 #define CLIPFS_ABI_VERSION 1
 int clipfs_abi_version(void);
+/* sha256 prefixes (16 hex digits) of the sources the library was built from: all of csrc/ + this header, and the
+ * fp32 GEMM alone (gemm.hip, gemm_common.h, common.h).  "unstamped" when built without build.py. */
+const char* clipfs_source_stamp(void);
+const char* clipfs_gemm_source_stamp(void);
 /* human readable description of the last CLIPFS_EINVAL on this thread */
 const char* clipfs_last_error(void);
 
@@ -164,10 +168,12 @@ int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const float* dout, co
  * t[m, s*r + j] = sum_k drop_s(x)[m,k] * A[s*r + j, k]       (the "down" half of
  * lora_train_vlp.py:302: x @ (B@A)^T == (x @ A^T) @ B^T; the reference materialises B@A).
  * drop_s = Philox dropout of nn.Dropout(p) (:298-299), one independent stream per
- * segment s: stream id = stream_base + s, element (m,k) as documented in DESIGN.md;
- * p = 0 or seed == 0 disables dropout.  seg_mask bit s = 0 leaves t[:, s*r..] = 0. */
+ * segment s: stream id = stream_base + s, element (drow0 + m, k) as documented in DESIGN.md
+ * (drow0 = index of row 0 in the GLOBAL batch: a data-parallel shard draws the masks of the
+ * one-process run); p = 0 or seed == 0 disables dropout.  seg_mask bit s = 0 leaves t[:, s*r..] = 0. */
 int clipfs_lora_down(const float* x, const float* A, float* t, int rows, int width, int r, int nseg,
-                     unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, void* stream);
+                     unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
+                     void* stream);
 /* Backward of the adapter pair for one linear with nseg stacked segments:
  *   dt[m, s*r+j]  = scale * sum_n dy[m, s*segw + n] * B[s*segw + n, j]
  *   dB[s*segw+n,j] += scale * sum_m dy[m, s*segw+n] * t[m, s*r+j]
@@ -178,7 +184,7 @@ size_t clipfs_lora_bwd_work_floats(int rows, int width, int r, int nseg);
 int clipfs_lora_bwd(const float* dy, const float* x, const float* t, const float* A, const float* B,
                     float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
                     int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
-                    float* work, void* stream);
+                    uint32_t drow0, float* work, void* stream);
 
 /* --------------------------------------------------------- token assembly --
  * vit: x[b,0,:] = class_embedding + pos[0]; x[b, 1+P+i, :] = vpt[i]  (jclip/model.py:109-114,
@@ -296,6 +302,7 @@ typedef struct clipfs_tower {
   float lora_scale, lora_dropout;
   uint64_t dropout_seed;    /* 0 = no dropout (eval) */
   uint32_t dropout_stream0; /* stream id of layer 0 segment 0; layer l uses stream0 + 4*l + s */
+  uint32_t dropout_row0;    /* global index of this call's first token row (data-parallel shards); 0 otherwise */
   const clipfs_block* blocks; /* HOST array [layers] of device pointers */
   int weight_format;        /* format of the blocks' *_p copies: 0 none (exact fp32), 1 bf16 hi/lo, 2 f16 */
 } clipfs_tower;

@@ -5,6 +5,7 @@ without it.  Object files are cached under csrc/build/ and rebuilt when a source
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -27,17 +28,42 @@ def _newer(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _stamp(paths) -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def source_stamps():
+    """(whole-library stamp, fp32-GEMM stamp) of the sources in the tree -- what clipfs_source_stamp() /
+    clipfs_gemm_source_stamp() of a library built from them return."""
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "clipfs.h")]
+    # common.hip only carries the stamps themselves: leave it out so that a stamp does not depend on itself
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if s != "common.hip" and os.path.exists(os.path.join(CSRC, s))]
+    return (_stamp(sorted(srcs) + headers),
+            _stamp([os.path.join(CSRC, "gemm.hip"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "common.h")]))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "clipfs.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    lib_stamp, gemm_stamp = source_stamps()
+    stamp_file = os.path.join(CSRC, "build", "stamp.txt")
+    stamp_now = lib_stamp + " " + gemm_stamp
+    stamp_old = open(stamp_file).read().strip() if os.path.exists(stamp_file) else ""
     objs, jobs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, "build", s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _newer(obj, [src] + headers):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+        extra = []
+        if s == "common.hip":  # carries the source stamps: rebuilt whenever any source changed
+            extra = [f'-DCLIPFS_SOURCE_STAMP="{lib_stamp}"', f'-DCLIPFS_GEMM_STAMP="{gemm_stamp}"']
+        if force or _newer(obj, [src] + headers) or (extra and stamp_now != stamp_old):
+            jobs.append([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -52,6 +78,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _newer(OUT, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    with open(stamp_file, "w") as f:
+        f.write(stamp_now + "\n")
     return OUT
 
 

@@ -53,7 +53,7 @@ class Tower(C.Structure):
     _fields_ = [
         ("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("seq", C.c_int), ("causal", C.c_int),
         ("lora_r", C.c_int), ("lora_scale", C.c_float), ("lora_dropout", C.c_float),
-        ("dropout_seed", C.c_uint64), ("dropout_stream0", C.c_uint32),
+        ("dropout_seed", C.c_uint64), ("dropout_stream0", C.c_uint32), ("dropout_row0", C.c_uint32),
         ("blocks", C.POINTER(Block)), ("weight_format", C.c_int),
     ]
 
@@ -66,6 +66,8 @@ _u, _u64, _u32 = C.c_uint, C.c_uint64, C.c_uint32
 SIGNATURES = {
     "clipfs_abi_version": (_i, []),
     "clipfs_last_error": (C.c_char_p, []),
+    "clipfs_source_stamp": (C.c_char_p, []),
+    "clipfs_gemm_source_stamp": (C.c_char_p, []),
     "clipfs_gemm_nt": (_i, [C.POINTER(GemmArgs), _p]),
     "clipfs_split_bf16": (_i, [_p, _p, _sz, _p]),
     "clipfs_convert_f16": (_i, [_p, _p, _sz, _p]),
@@ -83,9 +85,9 @@ SIGNATURES = {
     "clipfs_attention_lse_floats": (_sz, [_i, _i, _i]),
     "clipfs_attention_f16_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_attention_f16_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "clipfs_lora_down": (_i, [_p, _p, _p, _i, _i, _i, _i, _u, _f, _u64, _u32, _p]),
+    "clipfs_lora_down": (_i, [_p, _p, _p, _i, _i, _i, _i, _u, _f, _u64, _u32, _u32, _p]),
     "clipfs_lora_bwd_work_floats": (_sz, [_i, _i, _i, _i]),
-    "clipfs_lora_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _p, _p]),
+    "clipfs_lora_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _u32, _p, _p]),
     "clipfs_vit_fill_special": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clipfs_text_embed": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
     "clipfs_token_rows_grad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

@@ -71,7 +71,7 @@ class _TowerRT:
             self._planes[key] = pl
         return pl
 
-    def descriptor(self, train: bool, seed: int, seq: Optional[int] = None) -> Tower:
+    def descriptor(self, train: bool, seed: int, seq: Optional[int] = None, row0: int = 0) -> Tower:
         blocks = (Block * self.layers)()
         r, scale, p = 0, 0.0, 0.0
         for i, blk in enumerate(self.mod.resblocks):
@@ -120,6 +120,7 @@ class _TowerRT:
         # activations are saved: a no-grad forward in train mode (slow_pace.py:1659-1661) still drops
         t.dropout_seed = seed if p > 0 else 0
         t.dropout_stream0 = self.stream0
+        t.dropout_row0 = row0 * (seq or self.seq)  # first TOKEN row of this call in the global batch
         t.weight_format = {"fp32": 0, "bf16x3": 1, "fp16": 2}[self.precision]
         t.blocks = C.cast(blocks, C.POINTER(Block))
         t._blocks_keepalive = blocks  # ctypes array must outlive the call
@@ -142,13 +143,13 @@ class _TowerRT:
         return buf
 
     def forward(self, x: torch.Tensor, batch: int, train: bool, seed: int, seq: Optional[int] = None,
-                own_saved: bool = False):
+                own_saved: bool = False, row0: int = 0):
         """``train`` = keep the activations the backward needs.  ``own_saved``: give this call its OWN saved-activation
         tensor (the autograd route: several grad-enabled forwards of one tower may precede one backward, e.g. the 13
         caption chunks of encode_text_in_batches, lora_train_vlp.py:905-912); otherwise the per-tower cached buffer
         is reused (LoRATrainer: exactly one forward per backward)."""
         lib = _lib.load()
-        t = self.descriptor(train, seed, seq)
+        t = self.descriptor(train, seed, seq, row0)
         scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), x.device)
         saved = None
         if train:
@@ -160,9 +161,9 @@ class _TowerRT:
         return saved
 
     def backward(self, dx: torch.Tensor, batch: int, saved: torch.Tensor, seed: int, stop_at_input: bool,
-                 seq: Optional[int] = None):
+                 seq: Optional[int] = None, row0: int = 0):
         lib = _lib.load()
-        t = self.descriptor(True, seed, seq)
+        t = self.descriptor(True, seed, seq, row0)
         scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), dx.device)
         check(lib.clipfs_tower_bwd(C.byref(t), dx.data_ptr(), batch, saved.data_ptr(), scratch.data_ptr(),
                                    int(stop_at_input), torch.cuda.current_stream().cuda_stream), "tower_bwd")
@@ -206,7 +207,8 @@ class Engine:
         return _mix_seed(self.seed_base, self.step)
 
     # -- image tower --------------------------------------------------------------------------------
-    def vit_forward(self, images: torch.Tensor, train: bool, seed: int = 0, own_saved: bool = False):
+    def vit_forward(self, images: torch.Tensor, train: bool, seed: int = 0, own_saved: bool = False, row0: int = 0):
+        """``row0``: index of images[0] in the GLOBAL batch (data-parallel shard) -- only the dropout masks see it."""
         m = self.model
         v = m.visual
         assert images.is_cuda and images.dtype == torch.float32, "images: fp32 device tensor [B,3,R,R]"
@@ -226,7 +228,7 @@ class Engine:
         else:
             x = ops.layernorm_fwd(x0, v.ln_pre.weight.data, v.ln_pre.bias.data)
             mean0 = rstd0 = None
-        saved = self.vis.forward(x, B, train, seed, own_saved=own_saved)
+        saved = self.vis.forward(x, B, train, seed, own_saved=own_saved, row0=row0)
         if train:
             y, mean1, rstd1 = ops.layernorm_fwd(x, v.ln_post.weight.data, v.ln_post.bias.data, ldx=L * d, rows=B,
                                                 save_stats=True)
@@ -236,7 +238,7 @@ class Engine:
         feat = ops.gemm_nt(y, self.vproj_t)
         ctx = None
         if train:
-            ctx = dict(B=B, x_final=x, saved=saved, stats=(mean1, rstd1), seed=seed,
+            ctx = dict(B=B, x_final=x, saved=saved, stats=(mean1, rstd1), seed=seed, row0=row0,
                        pre=(x0, mean0, rstd0) if need_pre else None)
         return feat, ctx
 
@@ -249,7 +251,7 @@ class Engine:
         mean1, rstd1 = ctx["stats"]
         ops.layernorm_bwd(dy, ctx["x_final"], v.ln_post.weight.data, mean1, rstd1, ldx=L * d, dx=dx, lddx=L * d)
         has_vpt = v.VPT is not None
-        self.vis.backward(dx, B, ctx["saved"], ctx["seed"], stop_at_input=not has_vpt)
+        self.vis.backward(dx, B, ctx["saved"], ctx["seed"], stop_at_input=not has_vpt, row0=ctx["row0"])
         if has_vpt:
             x0, mean0, rstd0 = ctx["pre"]
             dx0 = ops.layernorm_bwd(dx, x0, v.ln_pre.weight.data, mean0, rstd0)
@@ -270,7 +272,7 @@ class Engine:
         return hit
 
     def text_forward(self, ids: torch.Tensor, prompt_ctx: Optional[torch.Tensor], train: bool, seed: int = 0,
-                     own_saved: bool = False):
+                     own_saved: bool = False, row0: int = 0):
         m = self.model
         ids = ids.to(device=m.device, dtype=torch.int64).contiguous()
         n, seq = ids.shape
@@ -279,7 +281,7 @@ class Engine:
         ids, seq = self._effective_ids(ids)
         x = ops.text_embed(ids, m.token_embedding.weight.data, m.positional_embedding.data,
                            None if prompt_ctx is None else prompt_ctx.data)
-        saved = self.txt.forward(x, n, train, seed, seq, own_saved=own_saved)
+        saved = self.txt.forward(x, n, train, seed, seq, own_saved=own_saved, row0=row0)
         rows, idx = ops.gather_eot(x, ids)
         if train:
             y, mean, rstd = ops.layernorm_fwd(rows, m.ln_final.weight.data, m.ln_final.bias.data, save_stats=True)
@@ -289,7 +291,7 @@ class Engine:
         feat = ops.gemm_nt(y, self.tproj_t)
         ctx = None
         if train:
-            ctx = dict(n=n, seq=seq, rows=rows, idx=idx, stats=(mean, rstd), saved=saved, seed=seed,
+            ctx = dict(n=n, seq=seq, rows=rows, idx=idx, stats=(mean, rstd), saved=saved, seed=seed, row0=row0,
                        has_ctx=prompt_ctx is not None)
         return feat, ctx
 
@@ -300,7 +302,7 @@ class Engine:
         mean, rstd = ctx["stats"]
         drows = ops.layernorm_bwd(dy, ctx["rows"], m.ln_final.weight.data, mean, rstd)
         dx = ops.scatter_rows(drows, ctx["idx"], seq)
-        self.txt.backward(dx, n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"], seq=seq)
+        self.txt.backward(dx, n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"], seq=seq, row0=ctx["row0"])
         if ctx["has_ctx"]:
             assert dctx_slot is not None
             ops.token_rows_grad(dx, dctx_slot, n, seq, 1)

@@ -178,17 +178,17 @@ def attention_bwd(qkv, dout, batch, seq, heads, causal, out=None, lse=None):
     return dqkv
 
 
-def lora_down(x, A, r, nseg, seg_mask=None, p=0.0, seed=0, stream_base=0):
+def lora_down(x, A, r, nseg, seg_mask=None, p=0.0, seed=0, stream_base=0, row0=0):
     rows, width = x.shape
     t = torch.empty(rows, nseg * r, device=x.device, dtype=torch.float32)
     if seg_mask is None:
         seg_mask = (1 << nseg) - 1
     check(_lib.load().clipfs_lora_down(_p(_f32(x)), _p(_f32(A)), _p(t), rows, width, r, nseg, seg_mask, p, seed,
-                                       stream_base, _stream()), "lora_down")
+                                       stream_base, row0, _stream()), "lora_down")
     return t
 
 
-def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_base=0, seg_mask=None):
+def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_base=0, seg_mask=None, row0=0):
     rows, width = x.shape
     nseg = dy.shape[1] // width
     r = B.shape[1]
@@ -200,7 +200,7 @@ def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_ba
     dt = torch.empty(rows, nseg * r, device=x.device, dtype=torch.float32)
     check(lib.clipfs_lora_bwd(_p(_f32(dy)), _p(_f32(x)), _p(_f32(t)), _p(_f32(A)), _p(_f32(B)), _p(dt), _p(dA),
                               _p(dB), _p(dx), rows, width, width, r, nseg, seg_mask, scale, p, seed, stream_base,
-                              _p(work), _stream()), "lora_bwd")
+                              row0, _p(work), _stream()), "lora_bwd")
     return dt
 
 
@@ -266,9 +266,11 @@ def l2norm_bwd(dy, y, inv):
     return dx
 
 
-def class_mean_fwd(emb, classes, templates):
+def class_mean_fwd(emb, classes, templates, out=None):
     width = emb.shape[1]
-    out = torch.empty(classes, width, device=emb.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(classes, width, device=emb.device, dtype=torch.float32)
+    assert out.is_contiguous() and tuple(out.shape) == (classes, width)
     check(_lib.load().clipfs_class_mean_fwd(_p(_f32(emb)), _p(out), classes, templates, width, _stream()),
           "class_mean_fwd")
     return out

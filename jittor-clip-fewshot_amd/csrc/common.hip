@@ -15,3 +15,14 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int clipfs_abi_version(void) { return CLIPFS_ABI_VERSION; }
 extern "C" const char* clipfs_last_error(void) { return clipfs::g_err; }
+
+// Source stamps baked in by build.py (sha256 prefixes of the kernel sources this library was built from): lets a
+// measurement file (profiles/*/gemm_traffic.json) state WHICH kernel it was taken on, and bench.py refuse a stale one.
+#ifndef CLIPFS_SOURCE_STAMP
+#define CLIPFS_SOURCE_STAMP "unstamped"
+#endif
+#ifndef CLIPFS_GEMM_STAMP
+#define CLIPFS_GEMM_STAMP "unstamped"
+#endif
+extern "C" const char* clipfs_source_stamp(void) { return CLIPFS_SOURCE_STAMP; }
+extern "C" const char* clipfs_gemm_source_stamp(void) { return CLIPFS_GEMM_STAMP; }

@@ -16,7 +16,7 @@ constexpr int LORA_MAX_OUT = 64;    // nseg * r
 __global__ __launch_bounds__(256) void lora_down_kernel(const float* __restrict__ x, const float* __restrict__ A,
                                                         float* __restrict__ t, int rows, int width, int r, int nseg,
                                                         unsigned seg_mask, float p, uint64_t seed,
-                                                        uint32_t stream_base) {
+                                                        uint32_t stream_base, uint32_t drow0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const float* __restrict_
       if (c < nch) {
         xs[i] = v[i];
         if (drop) {
-          const float4 m = dropout_scale4(seed, stream_base + s, (uint32_t)row, (uint32_t)c, thr, inv_keep);
+          const float4 m = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)row, (uint32_t)c, thr, inv_keep);
           xs[i].x *= m.x;
           xs[i].y *= m.y;
           xs[i].z *= m.z;
@@ -138,7 +138,7 @@ template <int R, int NSEG>
 __global__ __launch_bounds__(64) void lora_da_partial_kernel(const float* __restrict__ x, const float* __restrict__ dt,
                                                              float* __restrict__ part, int rows, int width,
                                                              unsigned seg_mask, float p, uint64_t seed,
-                                                             uint32_t stream_base, int rows_per_slice) {
+                                                             uint32_t stream_base, uint32_t drow0, int rows_per_slice) {
   const int c4 = blockIdx.x * 64 + threadIdx.x;  // chunk of 4 columns
   const int slice = blockIdx.y;
   if (c4 * 4 >= width) return;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) void lora_da_partial_kernel(const float* __rest
       if (!((seg_mask >> s) & 1u)) continue;
       float4 xs = xv;
       if (drop) {
-        const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)m, (uint32_t)c4, thr, inv_keep);
+        const float4 mk = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)m, (uint32_t)c4, thr, inv_keep);
         xs.x *= mk.x;
         xs.y *= mk.y;
         xs.z *= mk.z;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const float* __rest
 __global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ dt, const float* __restrict__ A,
                                                       float* __restrict__ dx, int rows, int width, int r, int nseg,
                                                       unsigned seg_mask, float p, uint64_t seed,
-                                                      uint32_t stream_base) {
+                                                      uint32_t stream_base, uint32_t drow0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ 
         a.w = fmaf(g, av.w, a.w);
       }
       if (drop) {
-        const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)row, (uint32_t)c, thr, inv_keep);
+        const float4 mk = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)row, (uint32_t)c, thr, inv_keep);
         a.x *= mk.x;
         a.y *= mk.y;
         a.z *= mk.z;
@@ -258,10 +258,10 @@ static inline int lora_slice_rows(int rows) {
 // lora_mfma.hip
 bool lora_mfma_ok(int width, int segw, int r, int nseg);
 int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
-                   float p, uint64_t seed, uint32_t stream_base, hipStream_t st);
+                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, hipStream_t st);
 int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                   float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
-                  float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st,
+                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
                   void (*reduce)(const float*, float*, size_t, int, float, hipStream_t));
 
 static void launch_reduce_slices(const float* part, float* out, size_t n, int slices, float scale, hipStream_t st) {
@@ -278,16 +278,16 @@ static bool use_lora_mfma() {
 using namespace clipfs;
 
 extern "C" int clipfs_lora_down(const float* x, const float* A, float* t, int rows, int width, int r, int nseg,
-                                unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, void* stream) {
+                                unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, void* stream) {
   CLIPFS_REQUIRE(x && A && t, "lora_down: null pointer");
   CLIPFS_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0 && width <= 256 * LORA_MAX_CHUNKS, "lora_down: width %d unsupported", width);
   CLIPFS_REQUIRE(r > 0 && r <= 64 && nseg > 0 && nseg <= 4 && nseg * r <= LORA_MAX_OUT, "lora_down: r %d nseg %d unsupported", r, nseg);
   CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_down: dropout p %f out of range", (double)p);
   CLIPFS_REQUIRE(aligned16(x) && aligned16(A), "lora_down: misaligned pointer");
   if (use_lora_mfma() && lora_mfma_ok(width, width, r, nseg))
-    return lora_down_mfma(x, A, t, rows, width, r, nseg, seg_mask, p, seed, stream_base, (hipStream_t)stream);
+    return lora_down_mfma(x, A, t, rows, width, r, nseg, seg_mask, p, seed, stream_base, drow0, (hipStream_t)stream);
   hipLaunchKernelGGL(lora_down_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, A, t, rows, width, r,
-                     nseg, seg_mask, p, seed, stream_base);
+                     nseg, seg_mask, p, seed, stream_base, drow0);
   return launch_status();
 }
 
@@ -302,7 +302,7 @@ extern "C" size_t clipfs_lora_bwd_work_floats(int rows, int width, int r, int ns
 template <int R>
 static int lora_bwd_r(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
                       float* dA, float* dB, float* dx, int rows, int width, int segw, int nseg, unsigned seg_mask,
-                      float scale, float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st) {
+                      float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st) {
   const int sr = lora_slice_rows(rows);
   const int slices = (rows + sr - 1) / sr;
   const int cols = nseg * segw;
@@ -324,11 +324,11 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
   switch (nseg) {
     case 1:
       hipLaunchKernelGGL((lora_da_partial_kernel<R, 1>), ga, dim3(64), 0, st, x, dt, part_a, rows, width, seg_mask, p,
-                         seed, stream_base, sr);
+                         seed, stream_base, drow0, sr);
       break;
     case 3:
       hipLaunchKernelGGL((lora_da_partial_kernel<R, 3>), ga, dim3(64), 0, st, x, dt, part_a, rows, width, seg_mask, p,
-                         seed, stream_base, sr);
+                         seed, stream_base, drow0, sr);
       break;
     default:
       set_error("lora_bwd: nseg %d unsupported (1 or 3)", nseg);
@@ -341,7 +341,7 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
   CLIPFS_CHECK(launch_status());
   if (dx) {
     hipLaunchKernelGGL(lora_dx_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, dt, A, dx, rows, width, R, nseg, seg_mask,
-                       p, seed, stream_base);
+                       p, seed, stream_base, drow0);
     CLIPFS_CHECK(launch_status());
   }
   return CLIPFS_OK;
@@ -349,7 +349,7 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
 
 extern "C" int clipfs_lora_bwd(const float* dy, const float* x, const float* t, const float* A, const float* B,
                                float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
-                               int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
+                               int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
                                float* work, void* stream) {
   CLIPFS_REQUIRE(dy && x && t && A && B && dt && dA && dB && work, "lora_bwd: null pointer");
   CLIPFS_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0 && segw == width, "lora_bwd: width %d segw %d unsupported (segw must equal width)", width, segw);
@@ -357,12 +357,12 @@ extern "C" int clipfs_lora_bwd(const float* dy, const float* x, const float* t, 
   CLIPFS_REQUIRE(aligned16(x) && aligned16(A) && aligned16(work) && (!dx || aligned16(dx)), "lora_bwd: misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
   if (use_lora_mfma() && lora_mfma_ok(width, segw, r, nseg) && aligned16(dy) && aligned16(dx ? dx : x))
-    return lora_bwd_mfma(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base,
+    return lora_bwd_mfma(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base, drow0,
                          work, st, launch_reduce_slices);
 #define CLIPFS_LORA_CASE(RR)                                                                                       \
   case RR:                                                                                                         \
     return lora_bwd_r<RR>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, nseg, seg_mask, scale, p, seed,       \
-                          stream_base, work, st)
+                          stream_base, drow0, work, st)
   switch (r) {
     CLIPFS_LORA_CASE(1);
     CLIPFS_LORA_CASE(2);

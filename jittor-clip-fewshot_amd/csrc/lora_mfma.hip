@@ -53,7 +53,7 @@ template <int NSEG>
 __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __restrict__ x, const float* __restrict__ A,
                                                              float* __restrict__ t, int rows, int width, int r,
                                                              unsigned seg_mask, float p, uint64_t seed,
-                                                             uint32_t stream_base) {
+                                                             uint32_t stream_base, uint32_t drow0) {
   __shared__ f32x4 red[3 * NSEG * 64];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = threadIdx.x >> 6;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __rest
       for (int u = 0; u < 4; ++u) {
         f32x4 xs = xv[u];
         if (drop) {
-          const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)m, (uint32_t)(((c0 + 16 * u) >> 2) + kg), thr, inv_keep);
+          const float4 mk = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)m, (uint32_t)(((c0 + 16 * u) >> 2) + kg), thr, inv_keep);
           xs[0] *= mk.x;
           xs[1] *= mk.y;
           xs[2] *= mk.z;
@@ -215,7 +215,7 @@ template <int NSEG>
 __global__ __launch_bounds__(256) void lora_da_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dt,
                                                            float* __restrict__ part, int rows, int width, int r,
                                                            unsigned seg_mask, float p, uint64_t seed,
-                                                           uint32_t stream_base, int rows_per_slice) {
+                                                           uint32_t stream_base, uint32_t drow0, int rows_per_slice) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
   if (k0 >= width) return;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void lora_da_mfma_kernel(const float* __restri
         if (!((seg_mask >> s) & 1u)) continue;
         f32x4 xs = xv[u];
         if (drop) {
-          const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)mcs[u], c4, thr, inv_keep);
+          const float4 mk = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)mcs[u], c4, thr, inv_keep);
           xs[0] *= mk.x;
           xs[1] *= mk.y;
           xs[2] *= mk.z;
@@ -286,7 +286,7 @@ template <int NSEG, int RQ>  // RQ = ceil(r / 4) MFMA K-steps
 __global__ __launch_bounds__(256) void lora_dx_mfma_kernel(const float* __restrict__ dt, const float* __restrict__ A,
                                                            float* __restrict__ dx, int rows, int width, int r,
                                                            unsigned seg_mask, float p, uint64_t seed,
-                                                           uint32_t stream_base) {
+                                                           uint32_t stream_base, uint32_t drow0) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * 16;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void lora_dx_mfma_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < RQ; ++q) acc = mfma16(av[u][s][q], dtv[s][q], acc);
         if (drop) {
-          const float4 mk = dropout_scale4(seed, stream_base + s, (uint32_t)mc, (uint32_t)(((k0 + 16 * u) >> 2) + kg), thr, inv_keep);
+          const float4 mk = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)mc, (uint32_t)(((k0 + 16 * u) >> 2) + kg), thr, inv_keep);
           acc[0] *= mk.x;
           acc[1] *= mk.y;
           acc[2] *= mk.z;
@@ -358,19 +358,19 @@ static int lora_mfma_slice_rows(int rows, int col_groups) {
 }
 
 int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
-                   float p, uint64_t seed, uint32_t stream_base, hipStream_t st) {
+                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, hipStream_t st) {
   const dim3 grid((rows + 15) / 16);
   if (nseg == 1)
-    hipLaunchKernelGGL((lora_down_mfma_kernel<1>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base);
+    hipLaunchKernelGGL((lora_down_mfma_kernel<1>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base, drow0);
   else
-    hipLaunchKernelGGL((lora_down_mfma_kernel<3>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base);
+    hipLaunchKernelGGL((lora_down_mfma_kernel<3>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base, drow0);
   return launch_status();
 }
 
 template <int NSEG>
 static int lora_bwd_mfma_n(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
                            float* dA, float* dB, float* dx, int rows, int width, int segw, int r, unsigned seg_mask,
-                           float scale, float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st,
+                           float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
                            void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
   const int cols = NSEG * segw;
   const int sr_b = lora_mfma_slice_rows(rows, cols / 64), slices_b = (rows + sr_b - 1) / sr_b;
@@ -387,7 +387,7 @@ static int lora_bwd_mfma_n(const float* dy, const float* x, const float* t, cons
   CLIPFS_CHECK(launch_status());
   float* part_a = work + (((size_t)slices_b * nb + 3) & ~(size_t)3);
   hipLaunchKernelGGL((lora_da_mfma_kernel<NSEG>), dim3((width + 255) / 256, slices_a), dim3(256), 0, st, x, dt, part_a, rows,
-                     width, r, seg_mask, p, seed, stream_base, sr_a);
+                     width, r, seg_mask, p, seed, stream_base, drow0, sr_a);
   CLIPFS_CHECK(launch_status());
   const size_t na = (size_t)NSEG * r * width;
   reduce(part_a, dA, na, slices_a, 1.0f, st);
@@ -395,16 +395,16 @@ static int lora_bwd_mfma_n(const float* dy, const float* x, const float* t, cons
   if (dx) {
     switch ((r + 3) / 4) {
       case 1:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 1>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 1>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
         break;
       case 2:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 2>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 2>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
         break;
       case 3:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 3>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 3>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
         break;
       default:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 4>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base);
+        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 4>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
         break;
     }
     CLIPFS_CHECK(launch_status());
@@ -414,12 +414,12 @@ static int lora_bwd_mfma_n(const float* dy, const float* x, const float* t, cons
 
 int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                   float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
-                  float p, uint64_t seed, uint32_t stream_base, float* work, hipStream_t st,
+                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
                   void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
   if (nseg == 1)
-    return lora_bwd_mfma_n<1>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
+    return lora_bwd_mfma_n<1>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
                               work, st, reduce);
-  return lora_bwd_mfma_n<3>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
+  return lora_bwd_mfma_n<3>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
                             work, st, reduce);
 }
 

@@ -197,7 +197,7 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
       CLIPFS_CHECK(clipfs_layernorm_fwd(x_in, d, b.ln1_g, b.ln1_b, h1, train ? sv + SL.stat1 : nullptr,
                                         train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
     if (qkv_mask)
-      CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, st));
+      CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, t->dropout_row0, st));
     const bool q16 = qkv_f16(t);
     CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
                       b.lora_b_qkv, r, 3, d, t->lora_scale, st, CHAIN_NONE, h16, q16 ? (void*)qkv : nullptr));
@@ -208,7 +208,7 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
       att16 = h16;
     } else
       CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
-    if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, st));
+    if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, t->dropout_row0, st));
     CLIPFS_CHECK(gemm(att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
                       1, d, t->lora_scale, st, CHAIN_NONE, att16));
     float* h2 = scratch + SC.h;
@@ -276,7 +276,7 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     if (lora_o) {
       CLIPFS_REQUIRE(b.g_lora_a_o && b.g_lora_b_o, "tower_bwd: block %d o-LoRA gradient slots missing", l);
       CLIPFS_CHECK(clipfs_lora_bwd(dx, sv + SL.att, sv + SL.t_o, b.lora_a_o, b.lora_b_o, dt, b.g_lora_a_o, b.g_lora_b_o,
-                                   datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, work, st));
+                                   datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, t->dropout_row0, work, st));
     }
     // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
     const void* dqkv16_ready = nullptr;
@@ -295,7 +295,7 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
       CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);
       CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
                                    b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
-                                   t->lora_dropout, seed, ds, work, st));
+                                   t->lora_dropout, seed, ds, t->dropout_row0, work, st));
     }
     if (need_dx) {
       if (h16)

@@ -462,13 +462,54 @@ class LoRATrainer:
         self.t = 0
         self.pg = process_group
         self.rank, self.world = D.world_info(process_group)
-        self.shard_text = shard_text and self.world > 1
+        self.shard_text = shard_text and (self.world > 1 or D.FORCE_COLLECTIVES)
         self.overlap_towers = True  # text tower on a side HIP stream (set False to serialise, e.g. for per-kernel timing)
+        # class-sharded text tower: fixed exchange buffers (allocated on first use, never re-zeroed: padding rows of
+        # the send block / the gradient table are written by nobody and stay zero)
+        self._xbuf = {}
+        self.collectives_per_step = (3 if self.shard_text else 1) if (self.world > 1 or D.FORCE_COLLECTIVES) else 0
+        self.time_collectives = False      # bench: bracket every collective with HIP events on the launch stream
+        self._coll_events = []
 
-    def forward_backward(self, images, captions, target, templates_per_class: int = 1, global_batch: Optional[int] = None):
-        """``images`` / ``target`` are THIS RANK's shard of the batch, ``captions`` the full caption table
-        [C * t, 77] (class major).  Accumulates gradients into the flat buffer; returns
-        (loss_sum_local [1], correct_local [1], logits_local [B_local, C])."""
+    # -- collectives ---------------------------------------------------------------------------------
+    def _exchange_buffers(self, classes: int, width: int):
+        from clipfs import dist as D
+        key = (classes, width)
+        b = self._xbuf.get(key)
+        if b is None:
+            s = D.block_rows(classes, self.world)
+            dev = self.flat.params.device
+            b = dict(S=s, send=torch.zeros(s, width, device=dev), full=torch.empty(self.world * s, width, device=dev),
+                     dfull=torch.zeros(self.world * s, width, device=dev), dmine=torch.empty(s, width, device=dev))
+            self._xbuf = {key: b}
+        return b
+
+    def _timed(self, name, fn):
+        if not self.time_collectives:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self._coll_events.append((name, e0, e1))
+        return out
+
+    def collective_times_ms(self):
+        """{name: [ms, ...]} of the collectives bracketed since the last call (needs a prior synchronize)."""
+        out = {}
+        for name, e0, e1 in self._coll_events:
+            out.setdefault(name, []).append(e0.elapsed_time(e1))
+        self._coll_events = []
+        return out
+
+    def forward_backward(self, images, captions, target, templates_per_class: int = 1, global_batch: Optional[int] = None,
+                         row_offset: int = 0):
+        """``images`` / ``target`` are THIS RANK's shard of the batch (rows ``row_offset ...`` of the global batch),
+        ``captions`` the full caption table [C * t, 77] (class major).  Accumulates gradients into the flat buffer;
+        returns (loss_sum_local [1], correct_local [1], logits_local [B_local, C]).
+
+        Collectives (world > 1, class-sharded text): all_gather of the class-feature block, reduce_scatter of its
+        gradient (here), all_reduce of the flat gradient (optimizer_step) -- clipfs/dist.py."""
         from clipfs import dist as D
         m = self.model
         eng = m.engine
@@ -477,7 +518,9 @@ class LoRATrainer:
         gb = global_batch or B * self.world
         t = templates_per_class
         classes = captions.shape[0] // t
-        c_lo, c_hi = D.shard_bounds(classes, self.rank, self.world) if self.shard_text else (0, classes)
+        d = m.embed_dim
+        c_lo, c_hi = D.block_bounds(classes, self.rank, self.world) if self.shard_text else (0, classes)
+        xb = self._exchange_buffers(classes, d) if self.shard_text else None
         # The two towers are independent until the logits: the text tower runs on a side HIP stream so that
         # its kernels fill the CUs the image tower's launches leave idle (small per-rank batches) and vice versa.
         main = torch.cuda.current_stream()
@@ -486,24 +529,29 @@ class LoRATrainer:
         emb = tctx = txt = None
         with torch.cuda.stream(side):
             if c_hi > c_lo:
-                emb, tctx = eng.text_forward(captions[c_lo * t:c_hi * t], self.prompt_ctx, True, seed)
-                txt = ops.class_mean_fwd(emb, c_hi - c_lo, t)
-        feat, ictx = eng.vit_forward(images, True, seed)
+                # dropout masks are indexed by GLOBAL rows (row0): a sharded run draws the masks of the one-process run
+                emb, tctx = eng.text_forward(captions[c_lo * t:c_hi * t], self.prompt_ctx, True, seed, row0=c_lo * t)
+                txt = ops.class_mean_fwd(emb, c_hi - c_lo, t, out=None if xb is None else xb["send"][:c_hi - c_lo])
+        feat, ictx = eng.vit_forward(images, True, seed, row0=row_offset)
         img_n, inv = ops.l2norm_fwd(feat, save_inv=True)
         main.wait_stream(side)
         if self.shard_text:
-            txt = D.allgather_rows(txt, c_lo, c_hi, classes, m.embed_dim, self.flat.params, self.pg)
+            full = self._timed("all_gather", lambda: D.allgather_blocks(xb["send"], xb["full"], self.pg))
+            txt = full[:classes]
         logits = ops.gemm_nt(img_n, txt, alpha=self.logit_scale)
         loss_sum, dl, correct = ops.cross_entropy(logits, target, True, grad_scale=B / gb)
-        d = img_n.shape[1]
         d_img_n = ops.matmul_small(dl, txt, B, d, classes, classes, 1, d, 1, self.logit_scale)
-        d_txt = ops.matmul_small(dl, img_n, classes, d, B, 1, classes, d, 1, self.logit_scale)
-        if self.shard_text:
-            D.allreduce_sum_(d_txt, self.pg)  # every rank needs the batch-total gradient of its classes
+        d_txt = ops.matmul_small(dl, img_n, classes, d, B, 1, classes, d, 1, self.logit_scale,
+                                 out=None if xb is None else xb["dfull"][:classes])
+        if self.shard_text:  # every rank needs the batch-total gradient of ITS classes only
+            mine = self._timed("reduce_scatter", lambda: D.reduce_scatter_blocks(xb["dfull"], xb["dmine"], self.pg))
+            d_txt_local = mine[:c_hi - c_lo]
+        else:
+            d_txt_local = d_txt
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if c_hi > c_lo:
-                d_emb = ops.class_mean_bwd(emb, d_txt[c_lo:c_hi].contiguous(), c_hi - c_lo, t)
+                d_emb = ops.class_mean_bwd(emb, d_txt_local, c_hi - c_lo, t)
                 slot = None if self.prompt_ctx is None else self.prompt_ctx.grad_slot
                 eng.text_backward(tctx, d_emb, slot)
         eng.vit_backward(ictx, ops.l2norm_bwd(d_img_n, img_n, inv))
@@ -518,18 +566,17 @@ class LoRATrainer:
     def optimizer_step(self):
         from clipfs import dist as D
         grad_scale = 1.0
-        if self.world > 1:
-            D.allreduce_sum_(self.flat.grads, self.pg)
-            if not self.shard_text:
-                # replicated text tower: every rank computed the same text gradients from ITS images only;
-                # the sum over ranks is already the batch total (d_txt is linear in the local dlogits).
-                pass
+        if self.world > 1 or D.FORCE_COLLECTIVES:
+            # replicated text tower (shard_text=False): every rank back-propagated the text gradient of ITS images
+            # only, so this same sum is already the batch total (d_txt is linear in the local dlogits)
+            self._timed("all_reduce", lambda: D.allreduce_sum_(self.flat.grads, self.pg))
         self.t += 1
         ops.adamw(self.flat.params, self.flat.grads, self.flat.m, self.flat.v, self.t, self.lr, self.betas, self.eps,
                   self.wd, grad_scale)
 
-    def step(self, images, captions, target, templates_per_class: int = 1):
+    def step(self, images, captions, target, templates_per_class: int = 1, global_batch: Optional[int] = None,
+             row_offset: int = 0):
         self.flat.zero_grad()
-        out = self.forward_backward(images, captions, target, templates_per_class)
+        out = self.forward_backward(images, captions, target, templates_per_class, global_batch, row_offset)
         self.optimizer_step()
         return out

@@ -15,8 +15,26 @@ guide, reported as counted.  Infinity-Cache hits are included in both (the count
 """
 import collections
 import csv
+import importlib.util
 import json
+import os
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def stamps():
+    """(gemm source stamp of the tree = what the library built from it reports, git HEAD or None).  bench.py reports
+    ``roofline.traffic`` only when the stamp equals clipfs_gemm_source_stamp() of the library it loaded."""
+    spec = importlib.util.spec_from_file_location("clipfs_build", os.path.join(ROOT, "jittor-clip-fewshot_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        head = None
+    return mod.source_stamps()[1], head
 
 
 def per_launch(path, kernel_substr, counter):
@@ -33,7 +51,8 @@ def main():
     kern = sys.argv[4] if len(sys.argv) > 4 else "gemm_nt_kernel<64, 128, 3>"
     f_kib, nf = per_launch(fetch_csv, kern, "FETCH_SIZE")
     w_kib, nw = per_launch(write_csv, kern, "WRITE_SIZE")
-    res = {"kernel": kern, "launches_counted": [nf, nw],
+    gemm_stamp, head = stamps()
+    res = {"kernel": kern, "launches_counted": [nf, nw], "gemm_source_stamp": gemm_stamp, "git_head_when_processed": head,
            "fetch_bytes_per_launch": round(2 * f_kib * 1024), "write_bytes_per_launch": round(w_kib * 1024),
            "traffic_bytes_per_launch": round(2 * f_kib * 1024 + w_kib * 1024),
            "corrections": "FETCH_SIZE x2 (gfx950 wide-read undercount), KiB -> bytes, summed over XCDs; includes Infinity-Cache hits"}

@@ -1,6 +1,6 @@
 """N > 1 path on CPU: two gloo ranks run the SAME exchange pattern as LoRATrainer (clipfs/dist.py helpers:
-image shard + B_local/B_global loss scaling, class-sharded text tower with all-gather of the class features and
-a summed gradient, ONE all-reduce of the flat gradient) with the oracle as the compute, and must reproduce
+image shard + B_local/B_global loss scaling, class-sharded text tower with ONE all_gather_into_tensor of the class-feature
+blocks and ONE reduce_scatter_tensor of their gradient, ONE all-reduce of the flat gradient) with the oracle as the compute, and must reproduce
 the single-process gradients of the full batch."""
 import os
 import socket
@@ -54,13 +54,16 @@ def _rank_main(rank, world, port, shard_text, out_dir):
     B, Cn = img.shape[0], cap.shape[0]
     assert D.world_info() == (rank, world)
     lo, hi = D.shard_bounds(B, rank, world)
-    c_lo, c_hi = D.shard_bounds(Cn, rank, world) if shard_text else (0, Cn)
+    c_lo, c_hi = D.block_bounds(Cn, rank, world) if shard_text else (0, Cn)
+    S = D.block_rows(Cn, world)
     # text: my classes only, with grad
     pe = O.build_prompts(ctx, sd["token_embedding.weight"], cap[c_lo:c_hi])
     emb = O.encode_text(sd, cap[c_lo:c_hi], tl, 0.5, embeds=pe)
     txt_local = O.class_text_features(emb, list(range(c_hi - c_lo)), c_hi - c_lo).t()  # [c, d]
     if shard_text:
-        txt_full = D.allgather_rows(txt_local.detach(), c_lo, c_hi, Cn, cfg.embed_dim, txt_local.detach())
+        send = torch.zeros(S, cfg.embed_dim, dtype=torch.float64)
+        send[:c_hi - c_lo] = txt_local.detach()
+        txt_full = D.allgather_blocks(send)[:Cn]
     else:
         txt_full = txt_local.detach()
     txt_leaf = txt_full.clone().requires_grad_()
@@ -71,8 +74,11 @@ def _rank_main(rank, world, port, shard_text, out_dir):
     loss_local.backward()
     d_txt = txt_leaf.grad.clone()
     if shard_text:
-        D.allreduce_sum_(d_txt)
-    txt_local.backward(d_txt[c_lo:c_hi] if shard_text else d_txt)
+        dfull = torch.zeros(world * S, cfg.embed_dim, dtype=torch.float64)
+        dfull[:Cn] = d_txt
+        txt_local.backward(D.reduce_scatter_blocks(dfull)[:c_hi - c_lo])
+    else:
+        txt_local.backward(d_txt)
     grads = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in flat] +
                       [ctx.grad.reshape(-1)])
     D.allreduce_sum_(grads)  # the single flat all-reduce

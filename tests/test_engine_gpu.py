@@ -543,3 +543,103 @@ def test_three_step_training_trajectory(dev, monkeypatch):
                 moved = max(moved, (want - torch.from_numpy(lw[f"layer_{i}"][names[pr]][nm]).double()).abs().max().item())
     worst = max(worst, _err(ctx_param, octx))
     assert moved > 1e-2 and worst < 2e-4, (moved, worst)
+
+
+def test_two_grad_forwards_before_one_backward(dev, monkeypatch):
+    """The reference's training loop makes 13 grad-enabled text forwards (chunks of 32 captions) before ONE backward
+    (encode_text_in_batches, lora_train_vlp.py:905-912,975): every forward of the autograd route must own its saved
+    activations.  Two caption chunks + two image chunks, cat, one backward == the single-pass gradient."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    cfg = synth.SMALL
+    sd, model = _build(cfg, dev)
+    args = _args("small", r=4, p=0.0)
+    layers = _apply(model, cfg, args, synth.synth_lora(cfg, 4, seed=5), monkeypatch)
+    L.mark_only_lora_as_trainable(model)
+    model.train()
+    img = synth.synth_images(6, cfg.image_resolution, seed=3).to(dev)
+    cap = synth.synth_captions(8, cfg.context_length, cfg.vocab_size, seed=4, max_len=12).to(dev)
+    gi = torch.randn(6, cfg.embed_dim, device=dev)
+    gt = torch.randn(8, cfg.embed_dim, device=dev)
+    params = [p for layer in layers for p, _ in layer.trainable_pairs()]
+
+    def grads(chunked):
+        for p in params:
+            p.grad = None
+        if chunked:  # same batch sizes on purpose: that is the case a per-tower cached buffer would alias
+            fi = torch.cat([model.encode_image(img[:3]), model.encode_image(img[3:])], 0)
+            ft = torch.cat([model.encode_text(cap[:4]), model.encode_text(cap[4:])], 0)
+        else:
+            fi, ft = model.encode_image(img), model.encode_text(cap)
+        ((fi * gi).sum() + (ft * gt).sum()).backward()
+        return [p.grad.detach().clone() for p in params]
+
+    one, two = grads(False), grads(True)
+    scale = max(g.abs().max().item() for g in one)
+    assert scale > 1e-3
+    worst = max((a - b).abs().max().item() for a, b in zip(one, two))
+    assert worst < 2e-5 * scale, (worst, scale)
+
+
+def test_encode_text_in_batches_is_differentiable(dev, monkeypatch):
+    """lora_train_vlp.py:905-917 is the differentiable text path of run_lora: the text-tower LoRA parameters must
+    receive a gradient through it (and the vision ones must not)."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    cfg = synth.VIT_B32  # real vocabulary: the function tokenizes strings
+    import dataclasses
+    cfg = dataclasses.replace(cfg, vision_layers=1, transformer_layers=2)
+    sd, model = _build(cfg, dev, seed=7)
+    args = _args("ViT-B/32", r=4, p=0.25)
+    layers = _apply(model, cfg, args, synth.synth_lora(cfg, 4, seed=5), monkeypatch)
+    L.mark_only_lora_as_trainable(model)
+    model.train()
+    emb = L.encode_text_in_batches(model, ["a photo of a cat.", "a photo of a dog.", "a diagram"], batch_size=2)
+    assert emb.requires_grad and emb.shape == (3, cfg.embed_dim)
+    emb.square().sum().backward()
+    nt = cfg.transformer_layers
+    for i, layer in enumerate(layers):
+        for p, _ in layer.trainable_pairs():
+            if i < nt:
+                assert p.grad is not None and p.grad.abs().max().item() > 0, f"text layer {i} got no gradient"
+            else:
+                assert p.grad is None
+
+
+def test_dropout_follows_train_mode_not_grad_mode(dev, monkeypatch):
+    """LinearLoRA.execute drops whenever is_training() (lora_train_vlp.py:297-298); the stage-2 loop calls a second
+    encode_image under jt.no_grad() in train mode (slow_pace.py:1659-1661), which is therefore dropout-ON.  The
+    no-grad route must produce the oracle's features for the engine's Philox masks; eval mode must not drop."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    from clipfs.engine import _mix_seed
+    from oracle import clip_oracle as O
+    cfg, p = synth.SMALL, 0.25
+    sd, model = _build(cfg, dev)
+    args = _args("small", r=4, p=p)
+    lw = synth.synth_lora(cfg, 4, seed=5)
+    _apply(model, cfg, args, lw, monkeypatch)
+    L.mark_only_lora_as_trainable(model)
+    B = 5
+    img = synth.synth_images(B, cfg.image_resolution, seed=3)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    _, vl = _oracle_lora(lw, cfg)
+    s = O.lora_scaling(1, 4)
+    model.train()
+    with torch.no_grad():
+        got = model.encode_image(img.to(dev))
+    seed = _mix_seed(model.engine.seed_base, model.engine.step)
+    vd = {}
+    for l in range(cfg.vision_layers):
+        vd[l] = {}
+        for k, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            keep = O.dropout_keep_mask(seed, 1000 + 4 * l + k, B * cfg.vision_tokens, cfg.vision_width, p)
+            vd[l][name] = (torch.from_numpy(keep).double() / (1 - p)).reshape(B, cfg.vision_tokens, -1).permute(1, 0, 2)
+    with torch.no_grad():
+        want_drop = O.encode_image(sd64, img.double(), vl, s, drops=vd)
+        want_eval = O.encode_image(sd64, img.double(), vl, s)
+    assert _err(got, want_drop) < 2e-5
+    assert _err(want_drop, want_eval) > 1e-4  # the masks matter
+    model.eval()
+    with torch.no_grad():
+        assert _err(model.encode_image(img.to(dev)), want_eval) < 2e-5
