@@ -151,7 +151,7 @@ def golden_top5(model, tr, dev):
     the first optimiser step (the golden holds the pristine shipped adapters)."""
     import numpy as np
     import torch
-    from clipfs import ops, synth
+    from clipfs import engine, ops, synth
     path = os.path.join(ROOT, "tests", "golden", "vitb32_full_step.npz")
     if not os.path.exists(path):
         return None
@@ -162,7 +162,7 @@ def golden_top5(model, tr, dev):
     model.eval()
     with torch.no_grad():
         fi = ops.l2norm_fwd(model.encode_image(img))
-        ft = ops.l2norm_fwd(model.encode_text(cap, tr.prompt_ctx))
+        ft = ops.l2norm_fwd(engine.encode_text(model, cap, tr.prompt_ctx))
         logits = ops.gemm_nt(fi, ft, alpha=100.0)
         top5 = ops.topk(logits, 5).cpu().numpy()
     model.train()

@@ -44,10 +44,10 @@ def _make(dev, p=0.0):
     names = {"q": "q_proj", "k": "k_proj", "v": "v_proj"}
     with torch.no_grad():
         for i, layer in enumerate(layers):
-            for p in "qkv":
-                m = getattr(layer, names[p])
-                m.w_lora_A.copy_(torch.from_numpy(lw[f"layer_{i}"][names[p]]["w_lora_A"]))
-                m.w_lora_B.copy_(torch.from_numpy(lw[f"layer_{i}"][names[p]]["w_lora_B"]))
+            for pr in "qkv":
+                m = getattr(layer, names[pr])
+                m.w_lora_A.copy_(torch.from_numpy(lw[f"layer_{i}"][names[pr]]["w_lora_A"]))
+                m.w_lora_B.copy_(torch.from_numpy(lw[f"layer_{i}"][names[pr]]["w_lora_B"]))
     ctx = torch.nn.Parameter(sd["token_embedding.weight"][[5, 6, 7, 8]].clone().to(dev))
     B, Cn = 8, 9
     img = synth.synth_images(B, cfg.image_resolution, seed=3).to(dev)
@@ -59,9 +59,9 @@ def _make(dev, p=0.0):
 def _rank_main(rank, world, port, shard_text, out_dir, p=0.0, backend="gloo", force=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for p in (os.path.join(root, "jittor-clip-fewshot_amd"), root):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    for path in (os.path.join(root, "jittor-clip-fewshot_amd"), root):
+        if path not in sys.path:
+            sys.path.insert(0, path)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     from clipfs import dist as D

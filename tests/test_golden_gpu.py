@@ -130,7 +130,8 @@ def test_vitb32_full_step_vs_golden(dev, golden_dir):
     tr = L.LoRATrainer(model, prompt_ctx=ctx)
     with torch.no_grad():
         fi = L.ops.l2norm_fwd(model.encode_image(img))
-        ft = L.ops.l2norm_fwd(model.encode_text(cap, ctx))
+        from clipfs.engine import encode_text
+        ft = L.ops.l2norm_fwd(encode_text(model, cap, ctx))
         ev = L.ops.gemm_nt(fi, ft, alpha=100.0)
     assert np.abs(ev.cpu().numpy() - z["eval_logits"]).max() < 1e-3
     assert np.array_equal(L.ops.topk(ev, 5).cpu().numpy(), z["eval_top5"])
