@@ -90,6 +90,9 @@ typedef struct clipfs_gemm_args {
   void* C_f16;             /* f16 x f16 kernel only: also (or, with C == NULL, only) write the result as f16, ld = ldc */
   int aux_f16;             /* f16 x f16 kernel only: aux_out / aux_in hold f16 values (fp16 storage of the saved
                               pre-activation), ld = ldc */
+  int* counters;           /* optional stream-K arrival counters: >= clipfs_gemm_counter_ints(M,N,K) ints, ZERO on entry
+                              (the kernel leaves them zero); with `workspace` enables the stream-K schedule */
+  size_t counters_ints;
 } clipfs_gemm_args;
 int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
 /* Products with few output tiles (small per-rank batches) are cut along K into `clipfs_gemm_splits` slices
@@ -105,6 +108,13 @@ int clipfs_split_bf16(const float* src, void* planes, size_t n, void* stream);
 int clipfs_convert_f16(const float* src, void* dst, size_t n, void* stream);
 int clipfs_gemm_splits(int M, int N, int K);
 size_t clipfs_gemm_workspace_floats(int M, int N, int K);
+/* Stream-K (opt-in: environment CLIPFS_GEMM_SK=1|2; dense fp32 products with K % 32 == 0, when `workspace` and `counters`
+ * are both supplied; clipfs_gemm_counter_ints returns 0 while it is off): the tiles x K-steps
+ * iteration space is cut into equal contiguous runs, one per resident workgroup, instead of one tile per workgroup
+ * (whose last round leaves most CUs idle at the path's 2-9 tiles per slot).  A tile shared by several runs is summed by
+ * the last run to arrive, in run order (bitwise reproducible, no float atomics, nobody waits).  `workspace` holds the
+ * partial-tile slabs, `counters` one arrival counter per tile: zeroed once by the caller, left zero by every launch. */
+size_t clipfs_gemm_counter_ints(int M, int N, int K);
 /* Diagnostics for bench.py's roofline leg (never enabled inside a timed region): while enabled, every
  * GEMM launch of the calling thread is bracketed by HIP events on its launch stream;
  * clipfs_gemm_timing_collect synchronises on them and returns the summed kernel time, the summed
@@ -305,11 +315,15 @@ typedef struct clipfs_tower {
   uint32_t dropout_row0;    /* global index of this call's first token row (data-parallel shards); 0 otherwise */
   const clipfs_block* blocks; /* HOST array [layers] of device pointers */
   int weight_format;        /* format of the blocks' *_p copies: 0 none (exact fp32), 1 bf16 hi/lo, 2 f16 */
+  int* gemm_counters;       /* optional: >= clipfs_tower_counter_ints(t, batch) ints, zeroed ONCE by the caller (every
+                               GEMM leaves them zero) -- enables the stream-K GEMM schedule; one buffer per stream */
+  size_t gemm_counters_ints;
 } clipfs_tower;
 
 /* floats needed per tower call for saved activations / scratch */
 size_t clipfs_tower_saved_floats(const clipfs_tower* t, int batch);
 size_t clipfs_tower_scratch_floats(const clipfs_tower* t, int batch);
+size_t clipfs_tower_counter_ints(const clipfs_tower* t, int batch);
 /* x [batch*seq, width] in/out (residual stream, updated in place).  saved == NULL: inference
  * (nothing kept); else activations for clipfs_tower_bwd are written to `saved`. */
 int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, float* scratch, void* stream);

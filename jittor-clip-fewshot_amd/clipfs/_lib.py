@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("a_mode", C.c_int), ("img_res", C.c_int), ("patch", C.c_int), ("out_tokens", C.c_int),
         ("B_planes", C.c_void_p), ("b_format", C.c_int), ("workspace", C.c_void_p), ("workspace_floats", C.c_size_t),
         ("A_f16", C.c_void_p), ("C_f16", C.c_void_p), ("aux_f16", C.c_int),
+        ("counters", C.c_void_p), ("counters_ints", C.c_size_t),
     ]
 
 
@@ -55,6 +56,7 @@ class Tower(C.Structure):
         ("lora_r", C.c_int), ("lora_scale", C.c_float), ("lora_dropout", C.c_float),
         ("dropout_seed", C.c_uint64), ("dropout_stream0", C.c_uint32), ("dropout_row0", C.c_uint32),
         ("blocks", C.POINTER(Block)), ("weight_format", C.c_int),
+        ("gemm_counters", C.c_void_p), ("gemm_counters_ints", C.c_size_t),
     ]
 
 
@@ -73,6 +75,7 @@ SIGNATURES = {
     "clipfs_convert_f16": (_i, [_p, _p, _sz, _p]),
     "clipfs_gemm_splits": (_i, [_i, _i, _i]),
     "clipfs_gemm_workspace_floats": (_sz, [_i, _i, _i]),
+    "clipfs_gemm_counter_ints": (_sz, [_i, _i, _i]),
     "clipfs_gemm_timing": (_i, [_i]),
     "clipfs_gemm_timing_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "clipfs_gemm_timing_last_bytes": (C.c_double, []),
@@ -112,6 +115,7 @@ SIGNATURES = {
     "clipfs_tta_views": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p]),
     "clipfs_tower_saved_floats": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_scratch_floats": (_sz, [C.POINTER(Tower), _i]),
+    "clipfs_tower_counter_ints": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_fwd": (_i, [C.POINTER(Tower), _p, _i, _p, _p, _p]),
     "clipfs_tower_bwd": (_i, [C.POINTER(Tower), _p, _i, _p, _p, _i, _p]),
 }

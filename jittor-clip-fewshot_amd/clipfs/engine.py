@@ -142,6 +142,18 @@ class _TowerRT:
             self._bufs[key] = buf
         return buf
 
+    def _attach_counters(self, t: Tower, batch: int, device) -> None:
+        """Stream-K arrival counters of the tower's GEMMs: zeroed once here, left zero by every launch; one buffer per
+        tower (the two towers run on different streams)."""
+        n = _lib.load().clipfs_tower_counter_ints(C.byref(t), batch)
+        if n == 0:
+            return
+        buf = self._bufs.get(("counters", 0))
+        if buf is None or buf.numel() < n:
+            buf = torch.zeros(n, device=device, dtype=torch.int32)
+            self._bufs[("counters", 0)] = buf
+        t.gemm_counters, t.gemm_counters_ints = buf.data_ptr(), buf.numel()
+
     def forward(self, x: torch.Tensor, batch: int, train: bool, seed: int, seq: Optional[int] = None,
                 own_saved: bool = False, row0: int = 0):
         """``train`` = keep the activations the backward needs.  ``own_saved``: give this call its OWN saved-activation
@@ -150,6 +162,7 @@ class _TowerRT:
         is reused (LoRATrainer: exactly one forward per backward)."""
         lib = _lib.load()
         t = self.descriptor(train, seed, seq, row0)
+        self._attach_counters(t, batch, x.device)
         scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), x.device)
         saved = None
         if train:
@@ -164,6 +177,7 @@ class _TowerRT:
                  seq: Optional[int] = None, row0: int = 0):
         lib = _lib.load()
         t = self.descriptor(True, seed, seq, row0)
+        self._attach_counters(t, batch, dx.device)
         scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), dx.device)
         check(lib.clipfs_tower_bwd(C.byref(t), dx.data_ptr(), batch, saved.data_ptr(), scratch.data_ptr(),
                                    int(stop_at_input), torch.cuda.current_stream().cuda_stream), "tower_bwd")

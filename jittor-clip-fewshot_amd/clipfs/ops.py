@@ -28,6 +28,20 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+_COUNTERS = {}
+
+
+def _gemm_counters(device, n: int) -> torch.Tensor:
+    """Zeroed stream-K arrival counters for a stand-alone GEMM call: cached per (device, stream) -- launches on one
+    stream are ordered and every launch leaves the counters zero."""
+    key = (device.index, _stream())
+    buf = _COUNTERS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n, 4096), device=device, dtype=torch.int32)
+        _COUNTERS[key] = buf
+    return buf
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
             act: int = 0, aux_out=None, aux_in=None, alpha: float = 1.0, lora_t=None, lora_b=None,
             lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True, b_planes=None,
@@ -75,6 +89,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     if nws:
         ws = torch.empty(nws, device=b.device, dtype=torch.float32)
         g.workspace, g.workspace_floats = _p(ws), nws
+        ncnt = lib.clipfs_gemm_counter_ints(M, N, K)
+        if ncnt and a is not None and b_planes is None:
+            cnt = _gemm_counters(b.device, ncnt)
+            g.counters, g.counters_ints = _p(cnt), cnt.numel()
     check(lib.clipfs_gemm_nt(C.byref(g), _stream()), "gemm_nt")
     return out16 if only16 else out
 

@@ -25,6 +25,7 @@ namespace clipfs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // first-class vector: stays in VGPRs (HIP's float4 struct arrays went to scratch)
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 // 16-byte global -> LDS copy without a VGPR round trip (global_load_lds_dwordx4): the LDS destination is
 // wave-uniform base + lane * 16, the global source is per lane -- so the XOR swizzle goes on the SOURCE.
@@ -273,6 +274,325 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   finish_tiles<TM, TN>(g, p.patches, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), m0 + BM <= M && n0 + BN <= N, lane);
 }
 
+// ---- stream-K ------------------------------------------------------------------------------------------------
+// The path's shapes put 2.3 - 9.4 tiles on each of the 512 resident workgroup slots, so a one-tile-per-workgroup grid
+// ends in a mostly idle round (1200 tiles = 2.34 rounds run for 3: profiles/r01).  Here gridDim.x persistent
+// workgroups ("runs", two per CU) share the work evenly:
+//   * the LAST sk_tiles tiles (between one and two per run) form an iteration space tiles x K-steps that is cut into
+//     gridDim.x equal contiguous pieces -- a piece covers the end of one tile and the start of the next;
+//   * the tiles before them are dealt whole, round by round, in the same XCD-contiguous order as gemm_nt_kernel (the
+//     64 runs of an XCD work on 64 neighbouring tiles: shared A / B panels in that XCD's L2).
+// Whole tiles go through the fused epilogue directly.  A partial tile's raw accumulators go to a slab and the LAST
+// contributor to arrive (agent-scope arrival counter; nobody ever waits, so no residency assumption) adds the slabs in
+// run order -- bitwise reproducible whatever the arrival order -- and runs the same LoRA + epilogue code.  Slabs are
+// stored write-through (sc1) and read with sc1 loads: no release / acquire fence (cdna_hip_programming.md section 5,
+// "In-launch split-K reduction").  A run is ONE software pipeline: the first K-step of the next tile is fetched into
+// the free LDS stage while the current tile runs its last K-step and its epilogue.
+struct SkSeg {
+  int tile, kb, ke;
+};
+
+template <int BM, int BN, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  // 2 waves per SIMD: <= 256 registers
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WM = BM >= 64 ? 2 : 1;
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  constexpr int A_CHUNKS = BM * 8 / 256;
+  constexpr int B_CHUNKS = BN * 8 / 256;
+  constexpr int STAGE_FLOATS = (BM + BN) * BK;
+  constexpr int NV = TM * TN * 4;  // 16-byte vectors of accumulators per lane
+  constexpr int SLAB_BYTES = BM * BN * 4;
+
+  const clipfs_gemm_args& g = p.a;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave / WN, wn = wave % WN;
+  const int M = g.M, N = g.N;
+  const int nk = p.sk_nk;
+  const int runs = gridDim.x;
+  const int w = xcd_contiguous_unit();  // runs that are neighbours in the tile list sit on one XCD (shared L2 panels)
+  // NSTAGE LDS stages: the LDS-DMA runs NSTAGE - 1 K-steps ahead of the MFMAs (2 stages = one K-step = ~1.7 us of two
+  // workgroups' MFMAs; a third stage measured no gain at 64 x 128 and would cost the 128 x 128 tile its second workgroup)
+  int* flag = reinterpret_cast<int*>(smem + NSTAGE * STAGE_FLOATS);  // one word behind the stages
+
+  // ---- this run's work list: its piece of the stream-K iteration space first, then its whole tiles ----
+  const int q = p.sk_q, r = p.sk_r;                     // piece length q (+1 for the first r runs)
+  const int sk_it0 = w * q + min(w, r);
+  const int sk_it1 = sk_it0 + q + (w < r ? 1 : 0);
+  // whole tiles: XCD x owns dp tiles [x * dpx, (x+1) * dpx), dpx = dp_rounds * (runs / 8) (host: runs % 8 == 0 when dp_rounds > 0)
+  const int rpx = runs >> 3;
+  const int xcd = rpx > 0 ? w / rpx : 0, li = rpx > 0 ? w - xcd * rpx : 0;
+  struct Cursor {  // position in the work list; the loads run two K-steps ahead of the MFMAs, each side has its own
+    int it, rd;
+  };
+  auto next_seg = [&](Cursor& c, SkSeg& sg) -> bool {
+    if (c.it < sk_it1) {
+      const int t = c.it / nk;
+      sg.tile = p.sk_tile0 + t;
+      sg.kb = c.it - t * nk;
+      sg.ke = min(nk, sg.kb + (sk_it1 - c.it));
+      c.it += sg.ke - sg.kb;
+      return true;
+    }
+    if (c.rd < p.sk_dp_rounds) {
+      sg.tile = (xcd * p.sk_dp_rounds + c.rd) * rpx + li;
+      sg.kb = 0;
+      sg.ke = nk;
+      ++c.rd;
+      return true;
+    }
+    return false;
+  };
+  // run index holding stream-K iteration x / first iteration of run c
+  auto run_of = [&](int x) -> int { return x < r * (q + 1) ? x / (q + 1) : r + (x - r * (q + 1)) / q; };
+  auto begin_of = [&](int c) -> int { return c * q + min(c, r); };
+
+  const int fr = lane & 31, fh = lane >> 5;
+  const int swz = (fr >> 1) & 7;
+  int a_frag[TM], b_frag[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) a_frag[t] = (wm * (BM / WM) + t * 32 + fr) * BK;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) b_frag[t] = BM * BK + (wn * (BN / WN) + t * 32 + fr) * BK;
+
+  const int GM = p.gm, nbn = p.n_blocks_n;
+  const int mb_total = (M + BM - 1) / BM;
+  auto tile_origin = [&](int tile, int& m0, int& n0) {  // super-tiles of gm m-blocks x all n-blocks, m fastest
+    const int grp = tile / (GM * nbn);
+    const int rem = tile - grp * (GM * nbn);
+    const int gmh = min(GM, mb_total - grp * GM);
+    m0 = (grp * GM + rem % gmh) * BM;
+    n0 = (rem / gmh) * BN;
+  };
+  const float* ga_src[A_CHUNKS];
+  const float* gb_src[B_CHUNKS];
+  auto set_sources = [&](int m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) {
+      const int rr = 8 * (uw + 4 * i) + (lane >> 3);
+      const int c = (lane & 7) ^ ((rr >> 1) & 7);
+      ga_src[i] = g.A + (size_t)min(m0 + rr, M - 1) * g.lda + 4 * c;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) {
+      const int rr = 8 * (uw + 4 * i) + (lane >> 3);
+      const int c = (lane & 7) ^ ((rr >> 1) & 7);
+      gb_src[i] = g.B + (size_t)min(n0 + rr, N - 1) * g.ldb + 4 * c;
+    }
+  };
+  auto glds_stage = [&](int kt, int stage) __attribute__((always_inline)) {
+    float* s = smem + stage * STAGE_FLOATS;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_CHUNKS; ++i) glds16(ga_src[i] + k0, s + 8 * (uw + 4 * i) * BK);
+#pragma unroll
+    for (int i = 0; i < B_CHUNKS; ++i) glds16(gb_src[i] + k0, s + BM * BK + 8 * (uw + 4 * i) * BK);
+  };
+
+  // ---- the K-step, software pipelined by hand --------------------------------------------------------------------
+  // A K-step is four groups of 8 MFMAs (512 cycles of the SIMD's matrix pipe each); the fragments of group q+1 are read
+  // from LDS right after the first MFMAs of group q were issued, so their latency runs in the shadow of that group
+  // (hipcc left alone emits read -> wait -> 8 MFMAs, exposing ~100+ cycles per group whenever the SIMD's other wave is
+  // in a prologue / epilogue / barrier).  The workgroup barrier sits INSIDE the last group: once a wave holds its last
+  // fragments it has finished with the stage, waits for its own LDS-DMA of the next stage (issued a whole K-step ago),
+  // passes the barrier and reads the NEXT K-step's first fragments while its remaining six MFMAs drain.
+  struct Frag {
+    f32x4 a[TM], b[TN];
+  };
+  auto read_frag = [&](Frag& f, const float* st, int qq) __attribute__((always_inline)) {
+    const int ch = (((2 * qq + fh) ^ swz) << 2);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) f.a[t] = *reinterpret_cast<const f32x4*>(st + a_frag[t] + ch);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) f.b[t] = *reinterpret_cast<const f32x4*>(st + b_frag[t] + ch);
+  };
+
+  // ---- load side: walks the work list two K-steps ahead of the MFMA side ----
+  Cursor lcur = {sk_it0, 0};
+  SkSeg lseg;
+  bool lhave = next_seg(lcur, lseg);
+  if (!lhave) return;
+  int lkt = lseg.kb, lstage = 0, issued = 0;
+  {
+    int lm0, ln0;
+    tile_origin(lseg.tile, lm0, ln0);
+    set_sources(lm0, ln0);
+  }
+  const int abl = p.ablate;
+  auto issue_next = [&]() __attribute__((always_inline)) {  // LDS-DMA of the next K-step of the list (no-op at its end)
+    if (!lhave) return;
+    if (!(abl & 1) || issued < 2) glds_stage(lkt, lstage);
+    lstage = lstage == NSTAGE - 1 ? 0 : lstage + 1;
+    ++issued;
+    if (++lkt == lseg.ke) {
+      lhave = next_seg(lcur, lseg);
+      if (lhave) {
+        int lm0, ln0;
+        tile_origin(lseg.tile, lm0, ln0);
+        set_sources(lm0, ln0);
+        lkt = lseg.kb;
+      }
+    }
+  };
+
+  // ---- MFMA side ----
+  Cursor ccur = {sk_it0, 0};
+  SkSeg cur;
+  bool have = next_seg(ccur, cur);
+  int cstage = 0, done = 0;  // stage holding the current K-step; K-steps finished
+#pragma unroll
+  for (int i = 0; i < NSTAGE - 1; ++i) issue_next();
+  Frag f0, f1;
+  if (NSTAGE >= 3 && issued > 1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (A_CHUNKS + B_CHUNKS)) : "memory");  // the first K-step has landed (later ones may still travel)
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frag(f0, smem + cstage * STAGE_FLOATS, 0);
+  while (have) {
+    SkSeg nxt;
+    const bool have_n = next_seg(ccur, nxt);
+    int m0, n0;
+    tile_origin(cur.tile, m0, n0);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = 0.f;
+    auto mfma_part = [&](const Frag& f, int e0, int e1) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = e0; e < e1; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    };
+    const int n_steps = cur.ke - cur.kb;
+    for (int kt = 0; kt < n_steps; ++kt) {
+      // one K-step on stage `cstage`; on entry f0 = its group-0 fragments
+      issue_next();  // K-step done + NSTAGE - 1 -> the stage released at the barrier inside the previous K-step
+      const float* st = smem + cstage * STAGE_FLOATS;
+      const int nstage = cstage == NSTAGE - 1 ? 0 : cstage + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_part(f0, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(abl & 8)) read_frag(f1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_part(f0, 1, 4);
+      mfma_part(f1, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(abl & 8)) read_frag(f0, st, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_part(f1, 1, 4);
+      mfma_part(f0, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(abl & 8)) read_frag(f1, st, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_part(f0, 1, 4);
+      mfma_part(f1, 0, 1);  // needs the last fragments: this wave is done reading the stage
+      __builtin_amdgcn_sched_barrier(0);
+      ++done;
+      if (abl & 4) {
+        if (!(abl & 8)) read_frag(f0, smem + nstage * STAGE_FLOATS, 0);
+      } else if (issued > done) {  // another K-step follows (this tile's or the next one's): barrier INSIDE the last group
+        if (NSTAGE >= 3 && issued >= done + NSTAGE - 1)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (A_CHUNKS + B_CHUNKS)) : "memory");  // all but the youngest K-steps' LDS-DMA
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everybody's share of the next stage has landed, everybody is done with this one
+        asm volatile("" ::: "memory");
+        read_frag(f0, smem + nstage * STAGE_FLOATS, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_part(f1, 1, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      cstage = nstage;
+    }
+    const int mw = m0 + wm * (BM / WM), nw = n0 + wn * (BN / WN);
+    const bool full_tile = m0 + BM <= M && n0 + BN <= N;
+
+    if (abl & 16) {
+      if (acc[0][0][0] == 123.456f) g.C[0] = 1.f;  // keep the accumulators alive
+    } else if (cur.kb == 0 && cur.ke == nk) {
+      finish_tiles<TM, TN>(g, p.patches, acc, mw, nw, full_tile, lane);
+    } else {
+      // ---- partial tile: publish the slab WRITE-THROUGH (sc1 stores: no release fence, which would write back the
+      // whole XCD L2 -- full of everybody's freshly written C tiles -- once per slab), take a ticket ----
+      const int t_lo_it = (cur.tile - p.sk_tile0) * nk, t_hi_it = t_lo_it + nk - 1;
+      const int kind = sk_it0 > t_lo_it ? 0 : 1;  // the piece starts inside this tile (its head) / before it (its tail)
+      {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_part + ((size_t)(2 * w + kind)) * (BM * BN), 0, SLAB_BYTES,
+                                                         0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const f32x4 val = f32x4{acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, val), rs,
+                                                     (((i * TN + j) * 4 + v) * 256 + tid) * 16, 0, /*sc1*/ 16);
+            }
+      }
+      const int w_lo = run_of(t_lo_it), w_hi = run_of(t_hi_it);  // pieces contributing to this tile
+      const int nc = w_hi - w_lo + 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+      __syncthreads();                                    // ... before ONE lane signals
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(p.sk_cnt + cur.tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == nc - 1;
+        if (last) __hip_atomic_store(p.sk_cnt + cur.tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero again for the next launch
+        *flag = last;
+      }
+      __syncthreads();
+      if (*flag) {
+        // the reducer: slabs are added in run order, so the sum does not depend on who arrived last (two contributors,
+        // the usual case: a + b == b + a, the own slab stays in registers).  EVERY slab load is an sc1 load (bypasses
+        // this CU's L1, which no other CU's store ever refreshes), so no acquire fence is needed either.
+        if (nc > 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int rr = 0; rr < 16; ++rr) acc[i][j][rr] = 0.f;
+        }
+        for (int c = w_lo; c <= w_hi; ++c) {
+          if (nc == 2 && c == w) continue;
+          const int ckind = begin_of(c) > t_lo_it ? 0 : 1;
+          const auto rs = __builtin_amdgcn_make_buffer_rsrc(p.sk_part + ((size_t)(2 * c + ckind)) * (BM * BN), 0, SLAB_BYTES,
+                                                           0x00020000);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              f32x4 u[4];  // one 32 x 32 accumulator tile at a time (register budget of the 128 x 128 kernel)
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+                u[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     rs, (((i * TN + j) * 4 + v) * 256 + tid) * 16, 0, /*sc1*/ 16));
+#pragma unroll
+              for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * v + e] += u[v][e];
+            }
+        }
+        finish_tiles<TM, TN>(g, p.patches, acc, mw, nw, full_tile, lane);
+      }
+    }
+    cur = nxt;
+    have = have_n;
+  }
+}
+
 // split-K combine: C = epilogue( sum_s part[s] ), slabs added in index order (bitwise reproducible)
 __global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(const GemmParams p) {
   const clipfs_gemm_args& g = p.a;
@@ -319,6 +639,102 @@ static int launch(const GemmParams& p, hipStream_t stream) {
   return launch_status();
 }
 
+static int cu_count() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;  // MI355X
+  }
+  return n;
+}
+
+constexpr int SK_MIN_STEPS = 8;  // K-steps per run below which the slab hand-off would outweigh the balance it buys
+
+// Stream-K configuration.  OPT-IN (CLIPFS_GEMM_SK=1 by shape, 2 always; default 0).  Measured on MI355X (64 x 128 tiles,
+// 2 persistent workgroups per CU; scripts/ablate_gemm.py, same box): stand-alone, against one tile per workgroup, it gains
+// 2-3 % where a tile has >= 24 K-steps and the grid ends in a partial round (K = 1536 ... 3072 shapes), 5-15 % on the
+// per-rank shapes of the 8-GPU run (150 - 600 tiles), loses 1-9 % at K = 512 (the slab hand-off of a 13 us tile is not
+// paid back) -- cfg-2 shape mix 76.2 % vs 75.4 % of the fp32 MFMA peak.  INSIDE the train step it loses 1.7 % (2831 vs
+// 2882 img/s; per-rank batches: no difference): the two towers already run on two streams, so the idle CUs of one
+// GEMM's last round are filled by the other tower's kernels, while a persistent grid that owns every CU keeps them out.
+// 128 x 128 tiles (a third less LDS-DMA / LDS-read traffic per MFMA) and 3 workgroups per CU were both slower.
+struct SkConfig {
+  bool use;
+  int per_cu;  // persistent workgroups per CU
+};
+
+static inline int sk_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+static inline SkConfig sk_config(int M, int N, int K) {
+  static const int mode = sk_env("CLIPFS_GEMM_SK", 0);  // 0: never (one tile per workgroup), 1: by shape, 2: always
+  static const int per_cu = sk_env("CLIPFS_GEMM_SK_PER_CU", 2);
+  SkConfig c;
+  c.per_cu = per_cu > 0 ? per_cu : 2;
+  const long tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
+  const int nk = K / BK;
+  const long slots = (long)cu_count() * c.per_cu;
+  c.use = mode == 2 || (mode == 1 && (nk >= 24 || (tiles < 2 * slots && tiles * nk >= 2L * SK_MIN_STEPS * 64)));
+  return c;
+}
+
+// Schedule of a stream-K launch over `tiles` tiles of `nk` K-steps: `runs` persistent workgroups; the last `sk_tiles`
+// tiles (one to two per run) are cut evenly along tiles x K-steps, the others are dealt whole in `dp_rounds` rounds.
+struct SkPlan {
+  int runs, dp_rounds, tile0, sk_tiles, q, r;
+};
+
+static inline SkPlan sk_plan(long tiles, int nk, int per_cu) {
+  SkPlan s;
+  const long slots = (long)cu_count() * per_cu;
+  long runs = tiles * nk / SK_MIN_STEPS;
+  if (runs < tiles) runs = tiles;  // short K: never fewer runs than tiles (a run per tile is the plain schedule)
+  if (runs > slots) runs = slots;
+  if (runs > tiles * nk) runs = tiles * nk;
+  s.runs = (int)(runs < 1 ? 1 : runs);
+  s.dp_rounds = 0;
+  if ((s.runs & 7) == 0 && tiles >= 2L * s.runs) s.dp_rounds = (int)(tiles / s.runs) - 1;
+  s.tile0 = s.dp_rounds * s.runs;
+  s.sk_tiles = (int)(tiles - s.tile0);
+  const long iters = (long)s.sk_tiles * nk;
+  s.q = (int)(iters / s.runs);
+  s.r = (int)(iters % s.runs);
+  return s;
+}
+
+template <int BM, int BN, int NSTAGE>
+static int launch_sk(GemmParams& p, int per_cu, hipStream_t stream) {
+  const int mb = (p.a.M + BM - 1) / BM;
+  p.n_blocks_n = (p.a.N + BN - 1) / BN;
+  p.sk_nk = p.a.K / BK;
+  const SkPlan s = sk_plan((long)mb * p.n_blocks_n, p.sk_nk, per_cu);
+  p.sk_tile0 = s.tile0;
+  p.sk_dp_rounds = s.dp_rounds;
+  p.sk_q = s.q;
+  p.sk_r = s.r;
+  p.sk_part = p.a.workspace;
+  p.sk_cnt = p.a.counters;
+  // the stages + the flag word, padded so that exactly `per_cu` workgroups fit a CU's 160 KiB (the rest of the CU stays
+  // free for the other tower's LayerNorm / attention / LoRA kernels on the side stream)
+  size_t lds = NSTAGE * (size_t)(BM + BN) * BK * sizeof(float) + 64;
+  const size_t want = (size_t)(160 * 1024 / (per_cu + 1)) + 1024;
+  if (lds < want && want * per_cu <= 160 * 1024) lds = want;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<BM, BN, NSTAGE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, NSTAGE>), dim3(s.runs), dim3(256), lds, stream, p);
+  return launch_status();
+}
+
 }  // namespace clipfs
 
 using namespace clipfs;
@@ -349,9 +765,38 @@ extern "C" int clipfs_gemm_splits(int M, int N, int K) {
   return s;
 }
 
+static inline bool sk_enabled() {
+  static const bool on = sk_env("CLIPFS_GEMM_SK", 0) != 0;
+  return on;
+}
+
+// stream-K geometry of a dense [M,N,K] product: tiles (of the finer 64 x 128 tiling: bounds the counter array for either
+// tile height), floats of slab space (a head and a tail slab per run)
+static inline void sk_geometry(int M, int N, int K, long* tiles, size_t* slab_floats) {
+  const SkConfig c = sk_config(M, N, K);
+  *tiles = (long)((M + 63) / 64) * ((N + 127) / 128);
+  *slab_floats = c.use ? (size_t)2 * sk_plan(*tiles, K / BK, c.per_cu).runs * 64 * 128 : 0;
+}
+
 extern "C" size_t clipfs_gemm_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int s = clipfs_gemm_splits(M, N, K);
-  return s > 1 ? (size_t)s * M * N : 0;
+  size_t need = s > 1 ? (size_t)s * M * N : 0;
+  if (sk_enabled() && (K % BK) == 0) {  // stream-K: a head and a tail slab per run
+    long tiles;
+    size_t sk;
+    sk_geometry(M, N, K, &tiles, &sk);
+    need = sk > need ? sk : need;
+  }
+  return need;
+}
+
+extern "C" size_t clipfs_gemm_counter_ints(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || !sk_enabled() || (K % BK) != 0) return 0;
+  long tiles;
+  size_t slab;
+  sk_geometry(M, N, K, &tiles, &slab);
+  return slab ? (size_t)tiles : 0;
 }
 
 extern "C" int clipfs_gemm_timing(int enable) {
@@ -482,6 +927,16 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   if (tile_cfg == 2 && a.a_mode == 0 && (a.K % BK) == 0) {
     p.n_blocks_n = (a.N + 63) / 64;
     return launch<128, 64, 0>(p, s);
+  }
+  // dense, K % 32 == 0, scratch + counters supplied: stream-K (every run the same number of K-steps)
+  if (sk_enabled() && tile_cfg == 0 && a.a_mode == 0 && (a.K % BK) == 0 && a.workspace && a.counters &&
+      sk_config(a.M, a.N, a.K).use &&
+      (long)((a.M + 63) / 64) * ((a.N + 127) / 128) * 2 * (a.K / BK) < (1L << 30) &&
+      a.workspace_floats >= clipfs_gemm_workspace_floats(a.M, a.N, a.K) &&
+      a.counters_ints >= clipfs_gemm_counter_ints(a.M, a.N, a.K)) {
+    CLIPFS_REQUIRE(aligned16(a.workspace), "gemm: workspace must be 16-byte aligned");
+    p.splits = 1;
+    return launch_sk<64, 128, 2>(p, sk_config(a.M, a.N, a.K).per_cu, s);
   }
   p.n_blocks_n = (a.N + 127) / 128;
   if (gemm_bm(a.M, a.N) == 32 && a.a_mode == 0 && (a.K % BK) == 0) return launch<32, 128, 3>(p, s);

@@ -15,6 +15,14 @@ struct GemmParams {
   float* part;     // splits > 1: raw partial sums, slab s at part + s * M * N (row-major, ld = N)
   int gm;          // super-tile height in m-blocks (tile order: gm m-blocks x all n-blocks, m fastest)
   int ablate;      // tuning aid (CLIPFS_GEMM_ABLATE): 1 no global prefetch, 2 no LDS store, 4 no barrier -- WRONG RESULTS
+  // stream-K launch (gemm_sk_kernel): the tiles x K-steps iteration space is cut into gridDim.x equal contiguous runs
+  int sk_nk;        // K-steps per tile
+  int sk_tile0;     // first tile of the stream-K part (= number of tiles dealt whole)
+  int sk_dp_rounds; // whole tiles per run
+  int sk_q, sk_r;   // stream-K piece of run w: K-steps [w q + min(w, r), ...) of length q + (w < r)
+  float* sk_part;  // partial-tile slabs: slot (2 w + kind) of BM*BN floats, w = run index, kind 0 = the run's first
+                   // (head) tile, 1 = its last (tail) tile
+  int* sk_cnt;     // arrival counter per tile (zero on entry, zero again on exit)
 };
 
 constexpr int BK = 32;

@@ -47,6 +47,7 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
 
 struct ScratchLayout {
   size_t h, big, b3, b1, dt, work, gemm_ws, gemm_ws_floats, a16, c16, total;
+  size_t counter_ints;  // stream-K arrival counters the tower's largest GEMM needs (a separate, caller-zeroed buffer)
 };
 
 static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
@@ -60,13 +61,16 @@ static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
   S.dt = o;   o += al4(M * 4 * r);
   S.work = o; o += r ? al4(clipfs_lora_bwd_work_floats((int)M, (int)d, (int)r, 3)) : 0;
   // split-K scratch for the largest of the tower's GEMM shapes (0 unless the row count is small)
-  size_t ws = 0;
+  size_t ws = 0, cnt = 0;
   const int shapes[7][2] = {{3 * (int)d, (int)d}, {(int)d, (int)d}, {4 * (int)d, (int)d}, {(int)d, 4 * (int)d},
                             {(int)d, 3 * (int)d}, {4 * (int)d, (int)d}, {(int)d, (int)d}};
   for (int i = 0; i < 7; ++i) {
     const size_t w = clipfs_gemm_workspace_floats((int)M, shapes[i][0], shapes[i][1]);
+    const size_t c = clipfs_gemm_counter_ints((int)M, shapes[i][0], shapes[i][1]);
     ws = w > ws ? w : ws;
+    cnt = c > cnt ? c : cnt;
   }
+  S.counter_ints = cnt;
   S.gemm_ws = o; S.gemm_ws_floats = ws; o += al4(ws);
   // fp16 storage mode (weight_format 2): f16 images of the GEMM operands, M x 4d halves each
   S.a16 = o; o += t->weight_format == 2 ? al4(M * 2 * d) : 0;
@@ -88,42 +92,61 @@ static int check_tower(const clipfs_tower* t, int batch) {
   return CLIPFS_OK;
 }
 
-static thread_local float* g_ws = nullptr;  // split-K scratch of the tower call in progress (its scratch buffer)
-static thread_local size_t g_ws_floats = 0;
-static thread_local int g_b_format = 0;  // format of the blocks' 16-bit weight copies for the call in progress
-static thread_local void* g_a16 = nullptr;  // fp16 mode: f16 image of the A operand (converted per GEMM)
-static thread_local void* g_c16 = nullptr;  // fp16 mode: f16 output handed from one GEMM to the next
+// Per-call state of a tower pass (no hidden / thread-local state: everything a GEMM of the pass needs travels here)
+struct TowerCtx {
+  float* ws = nullptr;          // split-K / stream-K scratch (inside the call's scratch buffer)
+  size_t ws_floats = 0;
+  int* counters = nullptr;      // stream-K arrival counters (caller-zeroed; every launch leaves them zero)
+  size_t counters_ints = 0;
+  int b_format = 0;             // format of the blocks' 16-bit weight copies
+  void* a16 = nullptr;          // fp16 mode: f16 image of the A operand (converted per GEMM)
+  void* c16 = nullptr;          // fp16 mode: f16 output handed from one GEMM to the next
+};
+
+static TowerCtx make_ctx(const clipfs_tower* t, float* scratch, const ScratchLayout& SC) {
+  TowerCtx c;
+  c.ws = scratch + SC.gemm_ws;
+  c.ws_floats = SC.gemm_ws_floats;
+  c.counters = t->gemm_counters;
+  c.counters_ints = t->gemm_counters_ints;
+  c.b_format = t->weight_format;
+  c.a16 = t->weight_format == 2 ? scratch + SC.a16 : nullptr;
+  c.c16 = t->weight_format == 2 ? scratch + SC.c16 : nullptr;
+  return c;
+}
 
 enum GemmChain { CHAIN_NONE = 0, CHAIN_OUT16 = 1, CHAIN_IN16 = 2 };
 
 // chain: CHAIN_OUT16 = the result is only the next GEMM's A operand: in fp16 mode write it as f16 alone;
 //        CHAIN_IN16  = A is the previous GEMM's CHAIN_OUT16 result.
 // a16_ready: f16 image of A written by the producing kernel (LayerNorm / attention); NULL = convert here.
-static int gemm(const float* A, const float* B, const void* Bp, float* C, int M, int N, int K, const float* bias,
-                const float* res, int act, float* aux_out, const float* aux_in, const float* lt, const float* lb, int r,
-                int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE, const void* a16_ready = nullptr,
-                void* c16_only = nullptr) {
+static int gemm(const TowerCtx& cx, const float* A, const float* B, const void* Bp, float* C, int M, int N, int K,
+                const float* bias, const float* res, int act, float* aux_out, const float* aux_in, const float* lt,
+                const float* lb, int r, int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE,
+                const void* a16_ready = nullptr, void* c16_only = nullptr) {
   clipfs_gemm_args a = {};
   a.B_planes = Bp;
-  a.b_format = g_b_format;
-  a.workspace = g_ws;
-  a.workspace_floats = g_ws_floats;
+  a.b_format = cx.b_format;
+  a.workspace = cx.ws;
+  a.workspace_floats = cx.ws_floats;
+  a.counters = cx.counters;
+  a.counters_ints = cx.counters_ints;
   a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K;
   a.lda = K; a.ldb = K; a.ldc = N; a.alpha = 1.f;
   a.bias = bias; a.residual = res; a.ldres = N;
   a.act = act; a.aux_out = aux_out; a.aux_in = aux_in;
   a.lora_t = lt; a.lora_b = lb; a.lora_r = r; a.lora_nseg = nseg; a.lora_seg_width = segw; a.lora_scale = lscale;
-  if (g_b_format == 2 && Bp && g_a16 && (K % 32) == 0 && (!lt || (segw % 128 == 0 && r <= 16))) {
+  if (cx.b_format == 2 && Bp && cx.a16 && (K % 32) == 0 && (!lt || (segw % 128 == 0 && r <= 16))) {
     if (chain & CHAIN_IN16) {
-      a.A_f16 = g_c16;
+      a.A_f16 = cx.c16;
     } else if (a16_ready) {
       a.A_f16 = a16_ready;  // the producing kernel already wrote the f16 image
     } else {
-      CLIPFS_CHECK(clipfs_convert_f16(A, g_a16, (size_t)M * K, st));
-      a.A_f16 = g_a16;
+      CLIPFS_CHECK(clipfs_convert_f16(A, cx.a16, (size_t)M * K, st));
+      a.A_f16 = cx.a16;
     }
     if (chain & CHAIN_OUT16) {
-      a.C_f16 = g_c16;
+      a.C_f16 = cx.c16;
       a.C = nullptr;
     }
     a.aux_f16 = 1;  // fp16 storage of the saved pre-activation (only the f16 x f16 GEMMs read or write it)
@@ -151,6 +174,11 @@ extern "C" size_t clipfs_tower_scratch_floats(const clipfs_tower* t, int batch) 
   return scratch_layout(t, (size_t)batch * t->seq).total;
 }
 
+extern "C" size_t clipfs_tower_counter_ints(const clipfs_tower* t, int batch) {
+  if (!t || batch <= 0) return 0;
+  return scratch_layout(t, (size_t)batch * t->seq).counter_ints;
+}
+
 extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, float* scratch, void* stream) {
   CLIPFS_CHECK(check_tower(t, batch));
   CLIPFS_REQUIRE(x && scratch, "tower_fwd: null buffer");
@@ -159,11 +187,9 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
   const SavedLayout SL = saved_layout(t, (size_t)M);
   const ScratchLayout SC = scratch_layout(t, (size_t)M);
   const bool train = saved != nullptr;
-  g_ws = scratch + SC.gemm_ws;
-  g_ws_floats = SC.gemm_ws_floats;
-  g_b_format = t->weight_format;
-  g_a16 = t->weight_format == 2 ? scratch + SC.a16 : nullptr;
-  g_c16 = t->weight_format == 2 ? scratch + SC.c16 : nullptr;
+  const TowerCtx cx = make_ctx(t, scratch, SC);
+  CLIPFS_REQUIRE(!t->gemm_counters || t->gemm_counters_ints >= SC.counter_ints,
+                 "tower: gemm_counters holds %zu ints, %zu needed", t->gemm_counters_ints, SC.counter_ints);
   // dropout follows the caller's train MODE (is_training(), lora_train_vlp.py:297-298), carried by a non-zero seed;
   // `saved` only decides whether activations are kept (a no-grad forward in train mode still drops)
   const uint64_t seed = t->dropout_seed;
@@ -187,8 +213,8 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
     const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
 
     // fp16 storage mode: producers write the f16 image of every GEMM operand next to (or instead of) the fp32 tensor
-    void* h16 = g_a16;                                                        // [M, d] halves: ln1 / attention / ln2 / dx
-    void* dqkv16 = g_a16 ? (void*)((char*)g_a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
+    void* h16 = cx.a16;                                                        // [M, d] halves: ln1 / attention / ln2 / dx
+    void* dqkv16 = cx.a16 ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
     (void)dqkv16;
     if (h16)
       CLIPFS_CHECK(clipfs_layernorm_fwd_f16(x_in, d, b.ln1_g, b.ln1_b, h1, h16, train ? sv + SL.stat1 : nullptr,
@@ -199,7 +225,7 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
     if (qkv_mask)
       CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, t->dropout_row0, st));
     const bool q16 = qkv_f16(t);
-    CLIPFS_CHECK(gemm(h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
+    CLIPFS_CHECK(gemm(cx, h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
                       b.lora_b_qkv, r, 3, d, t->lora_scale, st, CHAIN_NONE, h16, q16 ? (void*)qkv : nullptr));
     const void* att16 = nullptr;
     if (f16_attention(t)) {
@@ -209,7 +235,7 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
     } else
       CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
     if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, t->dropout_row0, st));
-    CLIPFS_CHECK(gemm(att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
+    CLIPFS_CHECK(gemm(cx, att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
                       1, d, t->lora_scale, st, CHAIN_NONE, att16));
     float* h2 = scratch + SC.h;
     if (h16)  // only the f16 image is consumed (by the c_fc GEMM)
@@ -219,9 +245,9 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
       CLIPFS_CHECK(clipfs_layernorm_fwd(x_mid, d, b.ln2_g, b.ln2_b, h2, train ? sv + SL.stat2 : nullptr,
                                         train ? sv + SL.stat2 + M : nullptr, M, d, 1e-5f, st));
     float* gbuf = scratch + SC.big;
-    CLIPFS_CHECK(gemm(h2, b.w_fc, b.w_fc_p, gbuf, M, 4 * d, d, b.b_fc, nullptr, 1, train ? sv + SL.u : nullptr, nullptr, nullptr,
+    CLIPFS_CHECK(gemm(cx, h2, b.w_fc, b.w_fc_p, gbuf, M, 4 * d, d, b.b_fc, nullptr, 1, train ? sv + SL.u : nullptr, nullptr, nullptr,
                       nullptr, 0, 0, 0, 0.f, st, CHAIN_OUT16, h16));
-    CLIPFS_CHECK(gemm(gbuf, b.w_pr, b.w_pr_p, x_next, M, d, 4 * d, b.b_pr, x_mid, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+    CLIPFS_CHECK(gemm(cx, gbuf, b.w_pr, b.w_pr_p, x_next, M, d, 4 * d, b.b_pr, x_mid, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
                       0.f, st, CHAIN_IN16));
   }
   return CLIPFS_OK;
@@ -235,14 +261,12 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
   const int M = batch * t->seq, d = t->width, r = t->lora_r;
   const SavedLayout SL = saved_layout(t, (size_t)M);
   const ScratchLayout SC = scratch_layout(t, (size_t)M);
-  g_ws = scratch + SC.gemm_ws;
-  g_ws_floats = SC.gemm_ws_floats;
-  g_b_format = t->weight_format;
-  g_a16 = t->weight_format == 2 ? scratch + SC.a16 : nullptr;
-  g_c16 = t->weight_format == 2 ? scratch + SC.c16 : nullptr;
+  const TowerCtx cx = make_ctx(t, scratch, SC);
+  CLIPFS_REQUIRE(!t->gemm_counters || t->gemm_counters_ints >= SC.counter_ints,
+                 "tower: gemm_counters holds %zu ints, %zu needed", t->gemm_counters_ints, SC.counter_ints);
   const uint64_t seed = t->dropout_seed;
-  void* h16 = g_a16;                                                           // f16 image of dx (then of d ln-out ...)
-  void* dqkv16 = g_a16 ? (void*)((char*)g_a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
+  void* h16 = cx.a16;                                                           // f16 image of dx (then of d ln-out ...)
+  void* dqkv16 = cx.a16 ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
   if (h16) CLIPFS_CHECK(clipfs_convert_f16(dx, h16, (size_t)M * d, st));       // later images come from LayerNorm backward
   for (int l = t->layers - 1; l >= 0; --l) {
     const clipfs_block& b = t->blocks[l];
@@ -260,9 +284,9 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     float* dt = scratch + SC.dt;
     float* work = scratch + SC.work;
     // MLP: du = (dx Wpr) * gelu'(u) ; dh2 = du Wfc ; dx += LN2'(dh2)
-    CLIPFS_CHECK(gemm(dx, b.w_pr_t, b.w_pr_t_p, du, M, 4 * d, d, nullptr, nullptr, 2, nullptr, sv + SL.u, nullptr, nullptr, 0, 0, 0,
+    CLIPFS_CHECK(gemm(cx, dx, b.w_pr_t, b.w_pr_t_p, du, M, 4 * d, d, nullptr, nullptr, 2, nullptr, sv + SL.u, nullptr, nullptr, 0, 0, 0,
                       0.f, st, CHAIN_OUT16, h16));
-    CLIPFS_CHECK(gemm(du, b.w_fc_t, b.w_fc_t_p, dh, M, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
+    CLIPFS_CHECK(gemm(cx, du, b.w_fc_t, b.w_fc_t_p, dh, M, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
                       st, CHAIN_IN16));
     if (h16)
       CLIPFS_CHECK(clipfs_layernorm_bwd_f16(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, h16, d,
@@ -271,7 +295,7 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
       CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, d, M, d,
                                         st));
     // attention output projection
-    CLIPFS_CHECK(gemm(dx, b.w_o_t, b.w_o_t_p, datt, M, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
+    CLIPFS_CHECK(gemm(cx, dx, b.w_o_t, b.w_o_t_p, datt, M, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
                       st, CHAIN_NONE, h16));
     if (lora_o) {
       CLIPFS_REQUIRE(b.g_lora_a_o && b.g_lora_b_o, "tower_bwd: block %d o-LoRA gradient slots missing", l);
@@ -289,7 +313,7 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
                                         t->causal, st));
     const bool need_dx = !(l == 0 && stop_at_input);
     if (need_dx)
-      CLIPFS_CHECK(gemm(dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+      CLIPFS_CHECK(gemm(cx, dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
                         0.f, st, CHAIN_NONE, dqkv16_ready));
     if (qkv_mask) {
       CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);

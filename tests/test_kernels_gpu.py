@@ -495,3 +495,36 @@ def test_attention_f16_bwd(batch, seq, heads, causal):
     (ro * dout.double()).sum().backward()
     ref = x.grad
     assert (dqkv.double() - ref).abs().max().item() < 1e-2 * ref.abs().max().item()
+
+
+def test_stream_k_gemm_schedule_in_subprocess():
+    """The opt-in stream-K schedule (CLIPFS_GEMM_SK=2: persistent workgroups, partial tiles summed by the last arriver in
+    run order) is read from the environment once per process, so it is exercised in a child: results within fp32
+    rounding of an fp64 product, bitwise reproducible from call to call, epilogue options and ragged shapes included."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from clipfs import ops, _lib
+assert _lib.load().clipfs_gemm_counter_ints(1600, 768, 768) > 0, "stream-K is not on"
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(3)
+for M, N, K in ((1600, 768, 768), (12800, 768, 3072), (1000, 200, 96), (77, 512, 2048), (3927, 1536, 512), (4096, 4096, 1024)):
+    a = torch.randn(M, K, generator=g).to(dev); b = torch.randn(N, K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev); res = torch.randn(M, N, generator=g).to(dev)
+    o1 = ops.gemm_nt(a, b, bias=bias, residual=res, act=1, aux_out=torch.empty(M, N, device=dev))
+    o2 = ops.gemm_nt(a, b, bias=bias, residual=res, act=1, aux_out=torch.empty(M, N, device=dev))
+    u = a.double() @ b.double().t() + bias.double()
+    want = u * torch.sigmoid(1.702 * u) + res.double()
+    err = (o1.double() - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-5, (M, N, K, err)
+    assert torch.equal(o1, o2), (M, N, K)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CLIPFS_GEMM_SK="2")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(root, "jittor-clip-fewshot_amd")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
