@@ -300,6 +300,12 @@ __global__ __launch_bounds__(256) void attention_mfma_bwd_kv_kernel(const float*
 
 // ---- host side (called from attention.hip) ----------------------------------------------------------------
 
+// attention_mfma16.hip: 16-token tiles on v_mfma_f32_16x16x4_f32, every operand in LDS (sequences up to 96 tokens)
+bool attention16_enabled(int seq);
+int attention16_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal, hipStream_t st);
+int attention16_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv, float* work,
+                    int batch, int seq, int heads, int causal, hipStream_t st);
+
 bool attention_mfma_enabled() {
   static const int cfg = getenv("CLIPFS_ATTN_MFMA") ? atoi(getenv("CLIPFS_ATTN_MFMA")) : 1;  // 0: VALU kernels (A/B aid)
   return cfg != 0;
@@ -316,6 +322,7 @@ static size_t am_lds(int seq, int images, bool vectors) {
 }
 
 int attention_mfma_fwd(const float* qkv, float* out, float* lse, int batch, int seq, int heads, int causal, hipStream_t st) {
+  if (attention16_enabled(seq)) return attention16_fwd(qkv, out, lse, batch, seq, heads, causal, st);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_fwd_kernel),
@@ -329,6 +336,7 @@ int attention_mfma_fwd(const float* qkv, float* out, float* lse, int batch, int 
 
 int attention_mfma_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv, float* work,
                        int batch, int seq, int heads, int causal, hipStream_t st) {
+  if (attention16_enabled(seq)) return attention16_bwd(qkv, dout, out, lse, dqkv, work, batch, seq, heads, causal, st);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_bwd_q_kernel),
