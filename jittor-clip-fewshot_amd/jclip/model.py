@@ -152,6 +152,18 @@ class CLIP(nn.Module):
     def device(self):
         return self.visual.conv1.weight.device
 
+    # -- Jittor Module.save / Module.load (slow_pace.py:1711, test.py:1820) -----------------------------------------
+    def save(self, path: str) -> None:
+        """``clip_model.save('test_pkl/clip_model.pkl')``: every parameter under its dotted name (with adapters:
+        ``...attn.q_proj.weight`` / ``.bias`` / ``.w_lora_A`` / ``.w_lora_B`` ..., as the reference's module tree)."""
+        from clipfs import module_io
+        module_io.save_module(self, path)
+
+    def load(self, path: str) -> None:
+        from clipfs import module_io
+        module_io.load_module(self, path)
+        self.invalidate_engine()  # transposed / 16-bit weight copies of the engine are stale now
+
     def invalidate_engine(self):
         """Called when the module tree changes (apply_lora, FlatTrainables) so pointers are re-collected.  The
         engine's user-visible settings (precision mode, text trimming) carry over to the rebuilt engine."""

@@ -72,15 +72,29 @@ def get_lora_parameters(model, bias='none'):
 
 
 def mark_only_lora_as_trainable(model, bias: str = 'none') -> None:
-    """The HIP backward computes input gradients and adapter gradients only (frozen backbone), so
-    ``bias='all'`` / ``'lora_only'`` -- bias training -- raise NotImplementedError here, as does any
-    unknown mode in the reference."""
+    """lora_train_vlp.py:143-160: freeze everything whose name has no ``lora_``; ``bias='all'`` re-enables every
+    parameter named ``*bias*``, ``'lora_only'`` the bias of each LoRA-wrapped linear, anything else raises
+    NotImplementedError.  The flags are set exactly as the reference sets them (so ``get_lora_parameters`` /
+    optimiser parameter lists come out the same).  NOTE: the reference's own training loop never uses a mode other than
+    'none' (its optimiser is built from ``get_lora_parameters(model)``, lora_train_vlp.py:946); the fused HIP backward
+    computes adapter / prompt gradients only, so a bias enabled here receives no gradient from ``LoRATrainer`` -- which is
+    also what the reference does with it, since ``p.requires_grad_ = True`` (:151,:157) assigns an attribute instead of
+    calling the method."""
     for n, p in model.named_parameters():
         if 'lora_' not in n:
             p.requires_grad_(False)
     if bias == 'none':
         return
-    raise NotImplementedError("bias training is outside the accelerated path (SURVEY.md section 8a: frozen base weights)")
+    if bias == 'all':
+        for n, p in model.named_parameters():
+            if 'bias' in n:
+                p.requires_grad_(True)
+    elif bias == 'lora_only':
+        for m in model.modules():
+            if isinstance(m, LoRALayer) and getattr(m, 'bias', None) is not None:
+                m.bias.requires_grad_(True)
+    else:
+        raise NotImplementedError
 
 
 def lora_state_dict(model, bias: str = 'none'):
@@ -255,10 +269,38 @@ class PlainMultiheadAttentionLoRA(nn.Module, LoRALayer):
             out.append((self.proj.w_lora_B, self.grad_B_o))
         return out
 
+    @torch.no_grad()
     def forward(self, query, key=None, value=None, need_weights=False, attn_mask=None, **_):
-        raise NotImplementedError(
-            "PlainMultiheadAttentionLoRA runs inside the fused tower (model.encode_image / encode_text); "
-            "calling one block's attention directly is not part of the accelerated path")
+        """Direct call of one adapted attention block (lora_train_vlp.py:431-513): [L, N, d] in, ([L, N, d], None)
+        out, causal iff an ``attn_mask`` is given -- the same kernels the fused tower sequences (rank-r LoRA down
+        projection with the Philox dropout of train mode, QKV GEMM with the LoRA up-projection in its epilogue,
+        attention, output projection).  Inference only, like ``jclip.mha.MultiheadAttention.forward``: training
+        differentiates through ``encode_image`` / ``encode_text`` (the tower), not through single blocks."""
+        if need_weights:
+            raise NotImplementedError("attention weights are never materialised (need_weights=False only)")
+        L, N, d = query.shape
+        r = self.r
+        x = query.permute(1, 0, 2).reshape(N * L, d).contiguous().float()
+        p = float(self.dropout_rate) if self.training else 0.0
+        seed = 0
+        if p > 0:
+            self._direct_calls = getattr(self, "_direct_calls", 0) + 1
+            seed = (0x9E3779B97F4A7C15 * self._direct_calls + 0x5EED) & 0xFFFFFFFFFFFFFFFF or 1
+        qkv_mask = self.lora_mask & 7
+        if qkv_mask and r > 0:
+            t = ops.lora_down(x, self.lora_A_qkv, r, 3, seg_mask=qkv_mask, p=p, seed=seed, stream_base=0)
+            qkv = ops.gemm_nt(x, self.qkv_weight, bias=self.qkv_bias, lora_t=t, lora_b=self.lora_B_qkv, lora_seg_width=d,
+                              lora_scale=float(self.scaling))
+        else:
+            qkv = ops.gemm_nt(x, self.qkv_weight, bias=self.qkv_bias)
+        o = ops.attention_fwd(qkv, N, L, self.num_heads, attn_mask is not None)
+        if (self.lora_mask & 8) and r > 0:
+            t = ops.lora_down(o, self.lora_A_o, r, 1, p=p, seed=seed, stream_base=3)
+            y = ops.gemm_nt(o, self._o_w, bias=self._o_b, lora_t=t, lora_b=self.lora_B_o, lora_seg_width=d,
+                            lora_scale=float(self.scaling))
+        else:
+            y = ops.gemm_nt(o, self._o_w, bias=self._o_b)
+        return y.reshape(N, L, d).permute(1, 0, 2).contiguous(), None
 
     execute = forward
 
@@ -385,6 +427,57 @@ def solve_mta(image_features, text_features):
     text = text_features.t().contiguous().float()
     _, logits = ops.mta(image_features.contiguous().float().unsqueeze(0), text, want_mode=False)
     return logits
+
+
+@torch.no_grad()
+def evaluate_views(clip_model, views, target, textual_features):
+    """The per-batch body of evaluate_lora (:823-841) for ``n_img`` images at once: ``views`` [n_img, V, 3, R, R]
+    (view 0 = the centre view, the rest the random crops the loader stacks behind it), ``target`` [n_img],
+    ``textual_features`` [d, C] unit columns.  ONE image-tower pass over all n_img * V views, one MTA launch.
+    Returns the number of correct top-1 predictions (mta, centre view, view ensemble)."""
+    n_img, V = views.shape[:2]
+    text_cd = textual_features.t().contiguous().float()
+    feats = ops.l2norm_fwd(clip_model.encode_image(views.reshape(n_img * V, *views.shape[2:])).contiguous())
+    fv = feats.reshape(n_img, V, -1)
+    _, mta = ops.mta(fv, text_cd, want_mode=False)                       # solve_mta(...) = 100 * mode @ text  (:834)
+    base = ops.gemm_nt(fv[:, 0].contiguous(), text_cd)                   # image_features[0] @ textual_features (:835)
+    ens = ops.gemm_nt(fv.mean(dim=1).contiguous(), text_cd)              # (features @ text).mean(0) = mean(features) @ text (:837)
+    tgt = target.to(mta.device).long().view(-1)
+    return tuple(int((ops.topk(x.contiguous(), 1).long().view(-1) == tgt).sum().item()) for x in (mta, base, ens))
+
+
+@torch.no_grad()
+def evaluate_lora(args, clip_model, loader, templates=None, textual_features=None):
+    """lora_train_vlp.py:813-846: MTA / centre-view / view-ensemble top-1 accuracy (in %) over a loader that yields
+    ``(image [n,1,3,R,R] | [n,3,R,R], images [n,1,N,3,R,R] | [n,N,3,R,R], target, impath)`` -- the centre view and the N
+    random crops of each image.  The text classifier comes from ``templates`` ({class: [captions]}, the reference reads
+    them from the 'text_template' folder, :816-817) or is passed in as ``textual_features`` [d, C]."""
+    clip_model.eval()
+    if textual_features is None:
+        if templates is None:
+            raise ValueError("evaluate_lora needs `templates` ({class: [captions]}) or `textual_features` [d, C]")
+        textual_features = clip_classifier(templates, clip_model).squeeze(0).t()
+    dev = clip_model.device
+    acc = acc1 = acc2 = 0
+    tot = 0
+    for batch in loader:
+        image, images, target = batch[0], batch[1], batch[2]
+        image = torch.as_tensor(image).to(dev).float()
+        images = torch.as_tensor(images).to(dev).float()
+        if image.dim() == 5:
+            image = image.squeeze(1)                                     # :826
+        if images.dim() == 6:
+            images = images.squeeze(1)                                   # :827
+        if images.dim() == 4:                                            # the reference's batch-size-1 loader: [N,3,R,R]
+            images = images.unsqueeze(0)
+        views = torch.cat([image.unsqueeze(1), images], dim=1)           # jt.concat((image, images)), per image (:829)
+        target = torch.as_tensor(target).view(-1)
+        c = evaluate_views(clip_model, views, target, textual_features)
+        acc, acc1, acc2 = acc + c[0], acc1 + c[1], acc2 + c[2]
+        tot += views.shape[0]
+    if tot == 0:
+        raise ValueError("evaluate_lora: the loader yielded no images")
+    return 100.0 * acc / tot, 100.0 * acc1 / tot, 100.0 * acc2 / tot
 
 
 # ----------------------------------------------------------------------------------------------

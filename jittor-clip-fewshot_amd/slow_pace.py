@@ -82,6 +82,23 @@ class VLPromptLearner(nn.Module):
 
     execute = forward
 
+    # -- Jittor Module.save / Module.load (slow_pace.py:1712, test.py:1821) ------------------------------------------
+    def save(self, path: str) -> None:
+        """``prompt_learner.save('test_pkl/PromptLearner.pkl')``: the learnable ``ctx`` plus the tensors the reference's
+        module also holds as Vars (token_prefix / token_suffix / tokenized_prompts / fixed_embeddings), so that the
+        reference can read the file back."""
+        from clipfs import module_io
+        extra = [("token_prefix", self.token_prefix), ("token_suffix", self.token_suffix),
+                 ("tokenized_prompts", self.tokenized_prompts)]
+        if self.fixed_embeddings is not None:
+            extra.append(("fixed_embeddings", self.fixed_embeddings))
+        module_io.save_module(self, path, extra)
+
+    def load(self, path: str) -> None:
+        """Only ``ctx`` is state here: prefix / suffix embeddings are re-derived from the model's token embedding."""
+        from clipfs import module_io
+        module_io.load_module(self, path, ignore=("token_prefix", "token_suffix", "tokenized_prompts", "fixed_embeddings"))
+
 
 class TextEncoder(nn.Module):
     """slow_pace.py:828-848: ``TextEncoder(clip_model)(prompts, tokenized_prompts)`` -> [C, E];
@@ -159,6 +176,16 @@ class Channel_LP(nn.Module):
         return _ChannelLPFn.apply(f, self.scale1, self.bias1, self.fc.weight, self.fc.bias)
 
     execute = forward
+
+    def save(self, path: str) -> None:
+        """``channel_lp.save('test_pkl/channel.pkl')`` (slow_pace.py:1709): {scale1, bias1, fc.weight, fc.bias}."""
+        from clipfs import module_io
+        module_io.save_module(self, path)
+
+    def load(self, path: str) -> None:
+        """``channel_lp.load('test_pkl/channel.pkl')`` (test.py:1819)."""
+        from clipfs import module_io
+        module_io.load_module(self, path)
 
 
 def logit_normalize(logit: torch.Tensor) -> torch.Tensor:

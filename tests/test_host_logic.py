@@ -49,8 +49,16 @@ def test_apply_lora_order_filters_and_shipped_checkpoint(b32, golden_dir):
     L.mark_only_lora_as_trainable(b32)
     assert all(p.requires_grad == ("lora_" in n) for n, p in b32.named_parameters())
     assert set(L.lora_state_dict(b32)) == set(names)
+    # bias modes (lora_train_vlp.py:149-160): 'all' re-enables every *bias*, 'lora_only' the biases of the wrapped linears
+    L.mark_only_lora_as_trainable(b32, bias="all")
+    assert all(p.requires_grad == ("lora_" in n or "bias" in n) for n, p in b32.named_parameters())
+    L.mark_only_lora_as_trainable(b32, bias="lora_only")
+    on = {n for n, p in b32.named_parameters() if p.requires_grad and "lora_" not in n}
+    assert "transformer.resblocks.0.attn.q_proj.bias" in on and "visual.transformer.resblocks.3.attn.v_proj.bias" in on
+    assert not any("mlp" in n or "ln_" in n or "out_proj" in n for n in on)
     with pytest.raises(NotImplementedError):
-        L.mark_only_lora_as_trainable(b32, bias="all")
+        L.mark_only_lora_as_trainable(b32, bias="some")
+    L.mark_only_lora_as_trainable(b32)
     l0 = layers[0]
     assert l0.scaling == 0.5 and l0.q_proj.r == 4  # alpha / sqrt(r)
     assert torch.count_nonzero(l0.q_proj.w_lora_B) == 0  # B = 0 at init (:213)
@@ -150,3 +158,66 @@ def test_transforms_shapes():
     std = torch.tensor(clip.CLIP_STD).view(3, 1, 1)
     assert torch.allclose(b, (a - mean) / std, atol=1e-6)
     assert t3(img).shape == t4(img).shape == (3, 224, 224)
+
+
+def test_stage2_module_checkpoints_roundtrip(tmp_path):
+    """slow_pace.py:1709-1713 / test.py:1818-1821: ``channel_lp.save``, ``prompt_learner.save``, ``clip_model.save`` write
+    {dotted name: array} pickles; ``.load`` copies them back in place (views / flat buffers stay bound) and the files are
+    plain dicts readable without executing anything."""
+    import types
+    import lora_train_vlp as L
+    import slow_pace as S
+    from clipfs import safe_pkl, synth
+    from jclip.model import build_model
+    cpu = torch.device("cpu")
+    cfg = synth.TINY
+
+    def make(seed):
+        model = build_model(synth.synth_state_dict(cfg, seed=seed, perturb=True), device=cpu)
+        args = types.SimpleNamespace(encoder="both", position="all", backbone="tiny", params=["q", "v", "o"], r=2, alpha=1,
+                                     dropout_rate=0.0)
+        saved = L.INDEX_POSITIONS_TEXT["all"]
+        L.INDEX_POSITIONS_TEXT["all"] = list(range(cfg.transformer_layers))
+        L.INDEX_POSITIONS_VISION["tiny"] = {"all": list(range(cfg.vision_layers))}
+        try:
+            layers = L.apply_lora(args, model)
+        finally:
+            L.INDEX_POSITIONS_TEXT["all"] = saved
+            del L.INDEX_POSITIONS_VISION["tiny"]
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for layer in layers:
+                for p_, _ in layer.trainable_pairs():
+                    p_.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+        return model, layers
+
+    model, layers = make(3)
+    path = str(tmp_path / "test_pkl" / "clip_model.pkl")
+    model.save(path)
+    raw = safe_pkl.load(path)
+    assert isinstance(raw, dict) and all(isinstance(v, np.ndarray) for v in raw.values())
+    assert "transformer.resblocks.0.attn.q_proj.w_lora_A" in raw and "visual.conv1.weight" in raw
+    assert "transformer.resblocks.0.attn.k_proj.weight" in raw and "transformer.resblocks.0.attn.proj.w_lora_B" in raw
+    other, other_layers = make(4)
+    before = other_layers[0].lora_A_qkv.clone()
+    other.load(path)
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), other.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    assert not torch.equal(other_layers[0].lora_A_qkv, before)  # the stacked tensor behind the views was written
+    assert torch.equal(other_layers[0].lora_A_qkv, layers[0].lora_A_qkv)
+    with pytest.raises(FileNotFoundError):
+        other.load(str(tmp_path / "nope.pkl"))
+
+    head = S.Channel_LP(in_dim=cfg.embed_dim, n_classes=7, device=cpu)
+    with torch.no_grad():
+        head.scale1.add_(0.25)
+        head.bias1.sub_(0.5)
+    hp = str(tmp_path / "test_pkl" / "channel.pkl")
+    head.save(hp)
+    assert sorted(safe_pkl.load(hp)) == ["bias1", "fc.bias", "fc.weight", "scale1"]
+    head2 = S.Channel_LP(in_dim=cfg.embed_dim, n_classes=7, device=cpu)
+    head2.load(hp)
+    assert all(torch.equal(a, b) for a, b in zip(head.state_dict().values(), head2.state_dict().values()))
+    bad = S.Channel_LP(in_dim=cfg.embed_dim, n_classes=9, device=cpu)
+    with pytest.raises(ValueError, match="shape mismatch"):
+        bad.load(hp)

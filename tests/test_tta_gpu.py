@@ -174,3 +174,94 @@ def test_head_training_step(dev):
     for mine, ref in zip((head.scale1, head.bias1, head.fc.weight, head.fc.bias), p64):
         err = (mine.grad.double().cpu() - ref.grad).abs().max().item()
         assert err < 1e-4 * max(ref.grad.abs().max().item(), 1e-3), err
+
+
+def test_evaluate_lora_three_accuracies(dev, b32):
+    """lora_train_vlp.py:813-846: MTA / centre-view / view-ensemble top-1 accuracy from ONE encode pass, against the
+    oracle run image by image exactly as the reference loop does (loader batch size 1, views = centre + crops)."""
+    import lora_train_vlp as L
+    from oracle import clip_oracle as O
+    cfg, sd, model = b32
+    n_img, N, Cn = 5, 6, 13
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(n_img, 1, 3, 224, 224, generator=g)
+    centre = (base + 0.2 * torch.randn(n_img, 1, 3, 224, 224, generator=g)).contiguous()
+    crops = (base + 0.6 * torch.randn(n_img, N, 3, 224, 224, generator=g)).contiguous()
+    text = O.l2_normalize(torch.randn(Cn, 512, generator=g, dtype=torch.float64)).float()  # [C, d]
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want = [0, 0, 0]
+    target = []
+    for i in range(n_img):
+        views = torch.cat([centre[i], crops[i]], 0)
+        f = O.l2_normalize(O.encode_image(sd64, views.double())).float()
+        mta = O.solve_mta(f, text.t())
+        basel = f[0:1] @ text.t()
+        ens = (f @ text.t()).mean(dim=0, keepdim=True)
+        tgt = int(mta.argmax()) if i % 2 == 0 else int((mta.argmax() + 1) % Cn)  # a mix of hits and misses
+        target.append(tgt)
+        for k, x in enumerate((mta, basel, ens)):
+            want[k] += int(int(x.argmax()) == tgt)
+    # the reference's loader: (image [1,1,3,R,R], images [1,1,N,3,R,R], target, impath), one image per batch
+    loader = [(centre[i].unsqueeze(0), crops[i].unsqueeze(0).unsqueeze(0), torch.tensor([target[i]]), "x") for i in range(n_img)]
+    got = L.evaluate_lora(None, model, loader, textual_features=text.t().to(dev))
+    assert got == tuple(100.0 * w / n_img for w in want), (got, want)
+    # batched loader (several images per batch) gives the same numbers
+    loader2 = [(centre[:3], crops[:3], torch.tensor(target[:3]), "x"), (centre[3:], crops[3:], torch.tensor(target[3:]), "x")]
+    assert L.evaluate_lora(None, model, loader2, textual_features=text.t().to(dev)) == got
+    with pytest.raises(ValueError):
+        L.evaluate_lora(None, model, loader)
+
+
+def test_prompt_learner_checkpoint_roundtrip(dev, b32, golden_dir, tmp_path):
+    """prompt_learner.save / .load (slow_pace.py:1712, test.py:1821)."""
+    import os
+    import slow_pace as SP
+    from clipfs import safe_pkl
+    cfg, sd, model = b32
+    names = [ln.split()[0] for ln in open(os.path.join(golden_dir, "classes.txt"))][:5]
+    classnames = [n.split("_", 1)[1] if "_" in n else n for n in names]
+    pl = SP.VLPromptLearner(classnames, model)
+    with torch.no_grad():
+        pl.ctx.add_(0.01 * torch.randn(4, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(2)))
+    path = str(tmp_path / "test_pkl" / "PromptLearner.pkl")
+    pl.save(path)
+    raw = safe_pkl.load(path)
+    assert set(raw) == {"ctx", "token_prefix", "token_suffix", "tokenized_prompts"}
+    assert raw["token_prefix"].shape == (5, 1, 512) and raw["token_suffix"].shape == (5, 72, 512)
+    pl2 = SP.VLPromptLearner(classnames, model)
+    assert _err(pl2.ctx, pl.ctx) > 0
+    pl2.load(path)
+    assert _err(pl2.ctx, pl.ctx) == 0
+
+
+def test_adapted_attention_block_direct_call(dev, b32):
+    """PlainMultiheadAttentionLoRA.execute on [L, N, d] (lora_train_vlp.py:431-513) vs the oracle's mha_forward with the
+    same adapters, causal and not, q/k/v/o adapters, eval mode (no dropout); and train mode drops (output changes)."""
+    import lora_train_vlp as L
+    from oracle import clip_oracle as O
+    cfg, sd, model = b32
+    blk = model.transformer.resblocks[1]
+    plain = blk.attn
+    mha = L.PlainMultiheadAttentionLoRA(plain, enable_lora=["q", "k", "v", "o"], r=4, lora_alpha=1, dropout_rate=0.25, seed=3)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        mha.lora_B_qkv.copy_(0.05 * torch.randn(mha.lora_B_qkv.shape, generator=g))
+        mha.lora_B_o.copy_(0.05 * torch.randn(mha.lora_B_o.shape, generator=g))
+    d = 512
+    Lq, N = 77, 3
+    x = torch.randn(Lq, N, d, generator=g)
+    p64 = {k: v.double() for k, v in O._block_params(sd, "transformer", 1).items()}
+    names = {"q": "q_proj", "k": "k_proj", "v": "v_proj", "o": "proj"}
+    lora = {names[k]: {"w_lora_A": getattr(mha, names[k]).w_lora_A.detach().double().cpu(),
+                       "w_lora_B": getattr(mha, names[k]).w_lora_B.detach().double().cpu()} for k in "qkvo"}
+    mha.eval()
+    for causal in (False, True):
+        mask = O.build_causal_mask(Lq, torch.float64) if causal else None
+        want = O.mha_forward(x.double(), p64, 8, mask, lora, O.lora_scaling(1, 4))
+        got, w = mha(x.to(dev), x.to(dev), x.to(dev), need_weights=False, attn_mask=mask)
+        assert w is None and _err(got, want) < 5e-5
+    mha.train()
+    dropped, _ = mha(x.to(dev), attn_mask=None)
+    assert _err(dropped, want) > 1e-4
+    with pytest.raises(NotImplementedError):
+        mha(x.to(dev), need_weights=True)
