@@ -47,6 +47,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # algorithmic GFLOP per unit (SURVEY.md section 8d / BASELINE.md section 2)
 IMG_FWD, IMG_BWD = 8.8176 + 0.0221, 8.586 + 0.044
 TXT_FWD, TXT_BWD = 5.9595 + 0.0227, 5.959 + 0.045
+# Exact zeros the backward does not multiply: the heads read ONE row per sequence (class token / EOT token), so in the
+# LAST block the gradient is zero in every other row until the attention mixes rows again -- its MLP and output-projection
+# input-gradients (9 d^2 MACs per token) run on that one row (clipfs_tower_bwd_sparse).  Subtracted from the algorithmic
+# count so that step_tflops prices only work an exact implementation has to do (GFLOP per image / caption):
+IMG_BWD_ZERO = 9 * 768 * 768 * 2 * 49 / 1e9
+TXT_BWD_ZERO = 9 * 512 * 512 * 2 * 76 / 1e9
 
 
 def parse():
@@ -428,7 +434,9 @@ def main():
         elif args.forward_only:
             step_tflop = gb * IMG_FWD / 1e3
         else:
-            step_tflop = (gb * (IMG_FWD + IMG_BWD) + args.classes * (TXT_FWD + TXT_BWD)) / 1e3
+            dense_bwd = os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
+            step_tflop = (gb * (IMG_FWD + IMG_BWD - (0 if dense_bwd else IMG_BWD_ZERO)) +
+                          args.classes * (TXT_FWD + TXT_BWD - (0 if dense_bwd else TXT_BWD_ZERO))) / 1e3
         backend = D.backend_name()
         out = {
             "metric": "images/sec ViT-B/32 fwd+LoRA-bwd bs=256" if args.model == "b32" else
@@ -441,6 +449,8 @@ def main():
                                    "fwd+bwd on 403 captions + image tower fwd+bwd + 100*cos CE + AdamW"
                        if not args.forward_only else "ViT-B/32 image tower forward only (diagnostic)",
                        "global_batch": gb, "images_per_rank": n_img_local, "captions": args.classes,
+                       "last_block_backward": "dense (CLIPFS_DENSE_BWD=1)" if os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
+                       else "one row per sequence (the rows with non-zero gradient; exact)",
                        "lora_dropout": args.dropout, "tower_streams": 1 if args.serial_towers else 2, "text_positions": "trimmed-to-last-EOT" if args.trim_text else 77, "parallelism": f"dp{world}" + ("" if args.no_shard_text or world == 1 else "+class-sharded-text")},
             "algorithmic_tflop_per_step": round(step_tflop, 3),
             "step_tflops": round(step_tflop / (ms * 1e-3), 2),

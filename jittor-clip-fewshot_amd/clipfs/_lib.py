@@ -97,6 +97,8 @@ SIGNATURES = {
     "clipfs_matmul_small": (_i, [_p, _p, _p, _i, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long, _f, _p]),
     "clipfs_gather_eot": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_scatter_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "clipfs_gather_seq_rows": (_i, [_p, _sz, _p, _p, _i, _i, _i, _p]),
+    "clipfs_add_seq_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "clipfs_l2norm_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
     "clipfs_l2norm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "clipfs_class_mean_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -118,6 +120,7 @@ SIGNATURES = {
     "clipfs_tower_counter_ints": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_fwd": (_i, [C.POINTER(Tower), _p, _i, _p, _p, _p]),
     "clipfs_tower_bwd": (_i, [C.POINTER(Tower), _p, _i, _p, _p, _i, _p]),
+    "clipfs_tower_bwd_sparse": (_i, [C.POINTER(Tower), _p, _p, _p, _i, _p, _p, _i, _p]),
 }
 
 _lib = None

@@ -183,6 +183,22 @@ class _TowerRT:
                                    int(stop_at_input), torch.cuda.current_stream().cuda_stream), "tower_bwd")
 
 
+    def backward_sparse(self, dxs: torch.Tensor, rows: torch.Tensor, batch: int, saved: torch.Tensor, seed: int,
+                        stop_at_input: bool, seq: Optional[int] = None, row0: int = 0) -> torch.Tensor:
+        """Backward from a gradient that is non-zero in ONE row per sequence (``dxs`` [batch, width] at token ``rows``
+        [batch] int32): the class token of the image head, the EOT token of the text head.  Returns the dense gradient
+        wrt the tower input (uninitialised when ``stop_at_input``)."""
+        lib = _lib.load()
+        t = self.descriptor(True, seed, seq, row0)
+        self._attach_counters(t, batch, dxs.device)
+        scratch = self.buffer("scratch", lib.clipfs_tower_scratch_floats(C.byref(t), batch), dxs.device)
+        dx = torch.empty(batch * (seq or self.seq), self.width, device=dxs.device, dtype=torch.float32)
+        check(lib.clipfs_tower_bwd_sparse(C.byref(t), dxs.data_ptr(), rows.data_ptr(), dx.data_ptr(), batch, saved.data_ptr(),
+                                          scratch.data_ptr(), int(stop_at_input), torch.cuda.current_stream().cuda_stream),
+              "tower_bwd_sparse")
+        return dx
+
+
 class Engine:
     def __init__(self, model):
         self.model = model
@@ -261,16 +277,25 @@ class Engine:
         v = self.model.visual
         B, L, d = ctx["B"], v.tokens, v.width
         dy = ops.gemm_nt(dfeat.contiguous(), v.proj.data)  # [B, width] = dfeat @ proj^T
-        dx = torch.zeros(B * L, d, device=dfeat.device, dtype=torch.float32)
         mean1, rstd1 = ctx["stats"]
-        ops.layernorm_bwd(dy, ctx["x_final"], v.ln_post.weight.data, mean1, rstd1, ldx=L * d, dx=dx, lddx=L * d)
+        # only the class-token row of each image carries gradient (jclip/model.py:121-124): it stays compact [B, width]
+        # and the tower's last block works on B rows (clipfs_tower_bwd_sparse) -- no zero-filled [B*L, width] tensor
+        dcls = ops.layernorm_bwd(dy, ctx["x_final"], v.ln_post.weight.data, mean1, rstd1, ldx=L * d)
         has_vpt = v.VPT is not None
-        self.vis.backward(dx, B, ctx["saved"], ctx["seed"], stop_at_input=not has_vpt, row0=ctx["row0"])
+        dx = self.vis.backward_sparse(dcls, self._class_rows(B, dfeat.device), B, ctx["saved"], ctx["seed"],
+                                      stop_at_input=not has_vpt, row0=ctx["row0"])
         if has_vpt:
             x0, mean0, rstd0 = ctx["pre"]
             dx0 = ops.layernorm_bwd(dx, x0, v.ln_pre.weight.data, mean0, rstd0)
             P = (v.input_resolution // v.patch_size) ** 2
             ops.token_rows_grad(dx0, v.VPT.grad_slot, B, L, 1 + P)
+
+    def _class_rows(self, batch: int, device) -> torch.Tensor:
+        z = getattr(self, "_zero_rows", None)
+        if z is None or z.numel() < batch or z.device != device:
+            z = torch.zeros(max(batch, 256), device=device, dtype=torch.int32)
+            self._zero_rows = z
+        return z[:batch]
 
     # -- text tower --------------------------------------------------------------------------------
     def _effective_ids(self, ids: torch.Tensor):
@@ -315,8 +340,9 @@ class Engine:
         dy = ops.gemm_nt(dfeat.contiguous(), m.text_projection.data)
         mean, rstd = ctx["stats"]
         drows = ops.layernorm_bwd(dy, ctx["rows"], m.ln_final.weight.data, mean, rstd)
-        dx = ops.scatter_rows(drows, ctx["idx"], seq)
-        self.txt.backward(dx, n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"], seq=seq, row0=ctx["row0"])
+        # only the EOT row of each caption carries gradient (jclip/model.py:213-214)
+        dx = self.txt.backward_sparse(drows, ctx["idx"], n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"],
+                                      seq=seq, row0=ctx["row0"])
         if ctx["has_ctx"]:
             assert dctx_slot is not None
             ops.token_rows_grad(dx, dctx_slot, n, seq, 1)

@@ -92,6 +92,27 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   }
 }
 
+// out[c, :] = src[(c * seq + idx[c]) * ld + 0..width)  -- one row per sequence (the class token / the EOT token)
+__global__ __launch_bounds__(256) void gather_seq_rows_kernel(const float* __restrict__ src, size_t ld,
+                                                              const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                              int n, int seq, int width) {
+  const size_t total = (size_t)n * width;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % width), c = (int)(i / width);
+    out[i] = src[((size_t)c * seq + idx[c]) * ld + k];
+  }
+}
+
+// dx[(c * seq + idx[c]) * width + k] += src[c, k]
+__global__ __launch_bounds__(256) void add_seq_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                           float* __restrict__ dx, int n, int seq, int width) {
+  const size_t total = (size_t)n * width;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % width), c = (int)(i / width);
+    dx[((size_t)c * seq + idx[c]) * width + k] += src[i];
+  }
+}
+
 // ---- per class: normalise templates, mean, normalise (lora_train_vlp.py:978-990) ----  one wave per class
 __global__ __launch_bounds__(64) void class_mean_fwd_kernel(const float* __restrict__ emb, float* __restrict__ out,
                                                             int templates, int width) {
@@ -566,6 +587,21 @@ extern "C" int clipfs_scatter_rows(const float* dy, const int32_t* idx, float* d
   const size_t total = (size_t)n * seq * width;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, n, seq,
                      width);
+  return launch_status();
+}
+
+extern "C" int clipfs_gather_seq_rows(const float* src, size_t ld, const int32_t* idx, float* out, int n, int seq, int width,
+                                      void* stream) {
+  CLIPFS_REQUIRE(src && idx && out && n > 0 && seq > 0 && width > 0 && ld >= (size_t)width, "gather_seq_rows: bad args");
+  hipLaunchKernelGGL(gather_seq_rows_kernel, dim3(grid_for((size_t)n * width)), dim3(256), 0, (hipStream_t)stream, src, ld,
+                     idx, out, n, seq, width);
+  return launch_status();
+}
+
+extern "C" int clipfs_add_seq_rows(const float* src, const int32_t* idx, float* dx, int n, int seq, int width, void* stream) {
+  CLIPFS_REQUIRE(src && idx && dx && n > 0 && seq > 0 && width > 0, "add_seq_rows: bad args");
+  hipLaunchKernelGGL(add_seq_rows_kernel, dim3(grid_for((size_t)n * width)), dim3(256), 0, (hipStream_t)stream, src, idx, dx,
+                     n, seq, width);
   return launch_status();
 }
 

@@ -302,7 +302,6 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  
   constexpr int A_CHUNKS = BM * 8 / 256;
   constexpr int B_CHUNKS = BN * 8 / 256;
   constexpr int STAGE_FLOATS = (BM + BN) * BK;
-  constexpr int NV = TM * TN * 4;  // 16-byte vectors of accumulators per lane
   constexpr int SLAB_BYTES = BM * BN * 4;
 
   const clipfs_gemm_args& g = p.a;

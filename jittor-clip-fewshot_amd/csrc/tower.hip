@@ -8,6 +8,8 @@
 // backward needs are exactly the ones the forward had to produce anyway.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace clipfs {
 
 static inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
@@ -253,22 +255,18 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
   return CLIPFS_OK;
 }
 
-extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, const float* saved, float* scratch,
-                                int stop_at_input, void* stream) {
-  CLIPFS_CHECK(check_tower(t, batch));
-  CLIPFS_REQUIRE(dx && saved && scratch, "tower_bwd: null buffer");
-  hipStream_t st = (hipStream_t)stream;
+// blocks l_hi ... 0 of the backward; dx [batch*seq, width] in/out
+static int tower_bwd_range(const clipfs_tower* t, float* dx, int batch, const float* saved, float* scratch,
+                           int stop_at_input, hipStream_t st, int l_hi) {
   const int M = batch * t->seq, d = t->width, r = t->lora_r;
   const SavedLayout SL = saved_layout(t, (size_t)M);
   const ScratchLayout SC = scratch_layout(t, (size_t)M);
   const TowerCtx cx = make_ctx(t, scratch, SC);
-  CLIPFS_REQUIRE(!t->gemm_counters || t->gemm_counters_ints >= SC.counter_ints,
-                 "tower: gemm_counters holds %zu ints, %zu needed", t->gemm_counters_ints, SC.counter_ints);
   const uint64_t seed = t->dropout_seed;
   void* h16 = cx.a16;                                                           // f16 image of dx (then of d ln-out ...)
   void* dqkv16 = cx.a16 ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
   if (h16) CLIPFS_CHECK(clipfs_convert_f16(dx, h16, (size_t)M * d, st));       // later images come from LayerNorm backward
-  for (int l = t->layers - 1; l >= 0; --l) {
+  for (int l = l_hi; l >= 0; --l) {
     const clipfs_block& b = t->blocks[l];
     const float* sv = saved + (size_t)l * SL.total;
     CLIPFS_REQUIRE(b.w_pr_t && b.w_fc_t && b.w_o_t && b.w_qkv_t, "tower_bwd: block %d lacks transposed weights", l);
@@ -331,4 +329,84 @@ extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, con
     }
   }
   return CLIPFS_OK;
+}
+
+
+extern "C" int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, const float* saved, float* scratch,
+                                int stop_at_input, void* stream) {
+  CLIPFS_CHECK(check_tower(t, batch));
+  CLIPFS_REQUIRE(dx && saved && scratch, "tower_bwd: null buffer");
+  const ScratchLayout SC = scratch_layout(t, (size_t)batch * t->seq);
+  CLIPFS_REQUIRE(!t->gemm_counters || t->gemm_counters_ints >= SC.counter_ints,
+                 "tower: gemm_counters holds %zu ints, %zu needed", t->gemm_counters_ints, SC.counter_ints);
+  return tower_bwd_range(t, dx, batch, saved, scratch, stop_at_input, (hipStream_t)stream, t->layers - 1);
+}
+
+extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, const int32_t* rows, float* dx, int batch,
+                                       const float* saved, float* scratch, int stop_at_input, void* stream) {
+  CLIPFS_CHECK(check_tower(t, batch));
+  CLIPFS_REQUIRE(dxs && rows && dx && saved && scratch, "tower_bwd_sparse: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int seq = t->seq, M = batch * seq, d = t->width, r = t->lora_r, Ms = batch;
+  const SavedLayout SL = saved_layout(t, (size_t)M);
+  const ScratchLayout SC = scratch_layout(t, (size_t)M);
+  CLIPFS_REQUIRE(!t->gemm_counters || t->gemm_counters_ints >= SC.counter_ints,
+                 "tower: gemm_counters holds %zu ints, %zu needed", t->gemm_counters_ints, SC.counter_ints);
+  const int l = t->layers - 1;
+  const clipfs_block& b = t->blocks[l];
+  const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
+  static const bool force_dense = getenv("CLIPFS_DENSE_BWD") && atoi(getenv("CLIPFS_DENSE_BWD")) != 0;  // A/B aid
+  if (force_dense || t->weight_format == 2 || lora_o || seq < 8) {  // dense fall-back: the row gradients scattered into zeros
+    CLIPFS_CHECK(clipfs_scatter_rows(dxs, rows, dx, batch, seq, d, st));
+    return tower_bwd_range(t, dx, batch, saved, scratch, stop_at_input, st, l);
+  }
+  CLIPFS_REQUIRE(b.w_pr_t && b.w_fc_t && b.w_o_t && b.w_qkv_t, "tower_bwd: block %d lacks transposed weights", l);
+  const TowerCtx cx = make_ctx(t, scratch, SC);
+  const float* sv = saved + (size_t)l * SL.total;
+  // compact (one row per sequence) buffers live in the MLP scratch, which this block does not otherwise use:
+  // Ms (8 d + 4 d + 2) floats <= M 4 d for seq >= 3
+  float* u_s = scratch + SC.big;
+  float* du_s = u_s + (size_t)Ms * 4 * d;
+  float* xmid_s = du_s + (size_t)Ms * 4 * d;
+  float* dh_s = xmid_s + (size_t)Ms * d;
+  float* dxm_s = dh_s + (size_t)Ms * d;
+  float* datt_s = dxm_s + (size_t)Ms * d;
+  float* mean_s = datt_s + (size_t)Ms * d;
+  float* rstd_s = mean_s + al4((size_t)Ms);
+  // ---- MLP and output projection on the `batch` rows that carry gradient ----
+  CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.u, (size_t)4 * d, rows, u_s, Ms, seq, 4 * d, st));
+  CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.x_mid, (size_t)d, rows, xmid_s, Ms, seq, d, st));
+  CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.stat2, 1, rows, mean_s, Ms, seq, 1, st));
+  CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.stat2 + M, 1, rows, rstd_s, Ms, seq, 1, st));
+  CLIPFS_CHECK(gemm(cx, dxs, b.w_pr_t, b.w_pr_t_p, du_s, Ms, 4 * d, d, nullptr, nullptr, 2, nullptr, u_s, nullptr, nullptr, 0, 0, 0,
+                    0.f, st));
+  CLIPFS_CHECK(gemm(cx, du_s, b.w_fc_t, b.w_fc_t_p, dh_s, Ms, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+                    0.f, st));
+  CLIPFS_CHECK(clipfs_layernorm_bwd(dh_s, xmid_s, d, b.ln2_g, mean_s, rstd_s, dxs, dxm_s, d, Ms, d, st));
+  CLIPFS_CHECK(gemm(cx, dxm_s, b.w_o_t, b.w_o_t_p, datt_s, Ms, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+                    0.f, st));
+  // ---- attention and the QKV projection see every row again ----
+  float* dh = scratch + SC.h;
+  float* datt = scratch + SC.b1;
+  float* dqkv = scratch + SC.b3;
+  float* dt = scratch + SC.dt;
+  float* work = scratch + SC.work;
+  CLIPFS_CHECK(clipfs_scatter_rows(datt_s, rows, datt, batch, seq, d, st));
+  CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, seq, t->heads, t->causal, st));
+  const unsigned qkv_mask = b.lora_a_qkv ? (b.lora_mask & 7u) : 0u;
+  const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
+  const bool need_dx = !(l == 0 && stop_at_input);
+  if (need_dx)
+    CLIPFS_CHECK(gemm(cx, dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                      0, 0.f, st));
+  if (qkv_mask) {
+    CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);
+    CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv, b.g_lora_b_qkv,
+                                 need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale, t->lora_dropout,
+                                 t->dropout_seed, ds, t->dropout_row0, work, st));
+  }
+  if (!need_dx) return CLIPFS_OK;
+  CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_in, d, b.ln1_g, sv + SL.stat1, sv + SL.stat1 + M, nullptr, dx, d, M, d, st));
+  CLIPFS_CHECK(clipfs_add_seq_rows(dxm_s, rows, dx, batch, seq, d, st));  // the residual branch around the attention
+  return tower_bwd_range(t, dx, batch, saved, scratch, stop_at_input, st, l - 1);
 }
