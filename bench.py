@@ -379,6 +379,20 @@ def main():
     if world == 1 and not args.no_variants and not args.forward_only and args.model == "b32" and \
             args.precision == "fp32" and not args.trim_text:
         variants = {}
+        # the same step with every block's backward dense (the one-row-per-sequence gradient scattered into zeros first)
+        model.engine.sparse_backward = False
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        vdt = (time.perf_counter() - t1) / 3
+        model.engine.sparse_backward = True
+        variants["dense_last_block_backward"] = {
+            "value": round(gb / vdt, 2), "unit": "images/s", "ms_per_step": round(vdt * 1e3, 3),
+            "note": "identical gradients; the last block's MLP / out-proj input-gradients computed for all 12 800 + 31 031 rows "
+                    "although only the 256 class-token + 403 EOT rows are non-zero (what round 1 measured)"}
         for name, trim, prec, note in (
                 ("trim_text", True, "fp32", "exact fp32; text tower evaluated only up to the last EOT of the batch (positions "
                                             "after a caption's EOT cannot reach its feature under the causal mask)"),

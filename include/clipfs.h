@@ -54,6 +54,8 @@ const char* clipfs_last_error(void);
  *     if act == 1:  (aux_out[m,n] = v);  v = v * sigmoid(1.702 v)        QuickGELU, model.py:24-27
  *     if act == 2:  v = v * dQuickGELU(aux_in[m,n])                      backward of act 1
  *     v += residual[rm, n]                                               model.py:60-61
+ *     if act == 3:  v = max(v, 0)                                        ReLU after the residual add (the ResNet-50
+ *                                                                        bottleneck of the MoCo branch, slow_pace.py:1239)
  *     C[out_row(m), n] = v
  * a_mode 0: A is row-major [M,K] with leading dimension lda.
  * a_mode 1: A is an NCHW image batch [B,3,R,R]; row m = (b, py, px) patch, column
@@ -71,7 +73,7 @@ typedef struct clipfs_gemm_args {
   const float* bias;       /* [N] or NULL */
   const float* residual;   /* [*,N] (ld = ldres) or NULL */
   int ldres;
-  int act;                 /* 0 none, 1 QuickGELU, 2 multiply by dQuickGELU(aux_in) */
+  int act;                 /* 0 none, 1 QuickGELU, 2 multiply by dQuickGELU(aux_in), 3 ReLU (after the residual; fp32 only) */
   float* aux_out;          /* act 1: pre-activation copy (ld = ldc) or NULL */
   const float* aux_in;     /* act 2: saved pre-activation (ld = ldc) */
   const float* lora_t;     /* [M, lora_nseg * lora_r] or NULL */
@@ -223,6 +225,19 @@ int clipfs_scatter_rows(const float* dy, const int32_t* idx, float* dx, int n, i
 int clipfs_gather_seq_rows(const float* src, size_t ld, const int32_t* idx, float* out, int n, int seq, int width,
                            void* stream);
 int clipfs_add_seq_rows(const float* src, const int32_t* idx, float* dx, int n, int seq, int width, void* stream);
+
+/* ------------------------------------------------- MoCo ResNet-50 branch --
+ * Data movement of the frozen ResNet-50 feature extractor (slow_pace.py:1237-1271,1677-1680; forward only, NHWC
+ * activations; convolutions run as clipfs_gemm_nt with BatchNorm folded into weights / bias and ReLU = act 3):
+ *   nchw_to_nhwc : y[n,h,w,c] = x[n,c,h,w]
+ *   im2col_nhwc  : col[(n,ho,wo), (ky,kx,c)] = x[n, ho*stride-pad+ky, wo*stride-pad+kx, c] (0 outside), row length Kp
+ *                  (>= kh*kw*C, multiple of 4, tail zero) -- the A operand of the convolution's GEMM
+ *   maxpool3x3s2 : torchvision's MaxPool2d(3, 2, 1) on NHWC;   global_avgpool : mean over HW -> [N, C] */
+int clipfs_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, void* stream);
+int clipfs_im2col_nhwc(const float* x, float* col, int N, int H, int W, int C, int kh, int kw, int stride, int pad,
+                       int Kp, void* stream);
+int clipfs_maxpool3x3s2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int clipfs_global_avgpool_nhwc(const float* x, float* y, int N, int HW, int C, void* stream);
 
 /* ---------------------------------------------------------- head / loss --
  * y = x / ||x||_2 per row; inv_norm[row] saved (may be NULL).  jclip/model.py:222-224. */

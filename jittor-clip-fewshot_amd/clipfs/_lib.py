@@ -115,6 +115,10 @@ SIGNATURES = {
     "clipfs_mta_work_floats": (_sz, [_i, _i, _i, _i]),
     "clipfs_mta": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_tta_views": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p]),
+    "clipfs_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "clipfs_im2col_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "clipfs_maxpool3x3s2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "clipfs_global_avgpool_nhwc": (_i, [_p, _p, _i, _i, _i, _p]),
     "clipfs_tower_saved_floats": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_scratch_floats": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_counter_ints": (_sz, [C.POINTER(Tower), _i]),

@@ -214,6 +214,10 @@ class Engine:
         # the reference's rows EOT+1..76 (jclip/model.py:202-215 encodes all 77) are dead work.
         self.trim_text = False
         self._trim_cache = {}
+        # Backward from the one row per sequence that carries gradient (class token / EOT): the last block's row-wise
+        # products run on those rows only.  False = scatter the rows into a zero-filled tensor and run every block dense
+        # (identical gradients; kept as the A/B reference, bench.py reports it as a variant).
+        self.sparse_backward = True
 
     @property
     def precision(self) -> str:
@@ -282,8 +286,12 @@ class Engine:
         # and the tower's last block works on B rows (clipfs_tower_bwd_sparse) -- no zero-filled [B*L, width] tensor
         dcls = ops.layernorm_bwd(dy, ctx["x_final"], v.ln_post.weight.data, mean1, rstd1, ldx=L * d)
         has_vpt = v.VPT is not None
-        dx = self.vis.backward_sparse(dcls, self._class_rows(B, dfeat.device), B, ctx["saved"], ctx["seed"],
-                                      stop_at_input=not has_vpt, row0=ctx["row0"])
+        if self.sparse_backward:
+            dx = self.vis.backward_sparse(dcls, self._class_rows(B, dfeat.device), B, ctx["saved"], ctx["seed"],
+                                          stop_at_input=not has_vpt, row0=ctx["row0"])
+        else:
+            dx = ops.scatter_rows(dcls, self._class_rows(B, dfeat.device), L)
+            self.vis.backward(dx, B, ctx["saved"], ctx["seed"], stop_at_input=not has_vpt, row0=ctx["row0"])
         if has_vpt:
             x0, mean0, rstd0 = ctx["pre"]
             dx0 = ops.layernorm_bwd(dx, x0, v.ln_pre.weight.data, mean0, rstd0)
@@ -341,8 +349,12 @@ class Engine:
         mean, rstd = ctx["stats"]
         drows = ops.layernorm_bwd(dy, ctx["rows"], m.ln_final.weight.data, mean, rstd)
         # only the EOT row of each caption carries gradient (jclip/model.py:213-214)
-        dx = self.txt.backward_sparse(drows, ctx["idx"], n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"],
-                                      seq=seq, row0=ctx["row0"])
+        if self.sparse_backward:
+            dx = self.txt.backward_sparse(drows, ctx["idx"], n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"],
+                                          seq=seq, row0=ctx["row0"])
+        else:
+            dx = ops.scatter_rows(drows, ctx["idx"], seq)
+            self.txt.backward(dx, n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"], seq=seq, row0=ctx["row0"])
         if ctx["has_ctx"]:
             assert dctx_slot is not None
             ops.token_rows_grad(dx, dctx_slot, n, seq, 1)

@@ -877,7 +877,8 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   CLIPFS_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
   CLIPFS_REQUIRE((a.K & 3) == 0 && (a.ldb & 3) == 0 && aligned16(a.B), "gemm: K and ldb must be multiples of 4, B 16-byte aligned");
   CLIPFS_REQUIRE(a.ldb >= a.K && a.ldc >= a.N, "gemm: leading dimension too small");
-  CLIPFS_REQUIRE(a.act >= 0 && a.act <= 2, "gemm: bad act %d", a.act);
+  CLIPFS_REQUIRE(a.act >= 0 && a.act <= 3, "gemm: bad act %d", a.act);
+  CLIPFS_REQUIRE(a.act != 3 || !a.B_planes, "gemm: act 3 (ReLU) belongs to the exact fp32 kernels");
   CLIPFS_REQUIRE(a.act != 2 || a.aux_in, "gemm: act 2 needs aux_in");
   CLIPFS_REQUIRE(!a.residual || a.ldres >= a.N, "gemm: ldres too small");
   GemmParams p;

@@ -54,6 +54,7 @@ __device__ __forceinline__ void epilogue_store(const clipfs_gemm_args& g, int pa
     v *= quick_gelu_grad(g.aux_in[orow * g.ldc + n]);
   }
   if (g.residual) v += g.residual[rrow * g.ldres + n];
+  if (g.act == 3) v = fmaxf(v, 0.f);  // ReLU AFTER the residual add (ResNet bottleneck: relu(conv + identity))
   g.C[orow * g.ldc + n] = v;
 }
 
@@ -136,6 +137,10 @@ __device__ __forceinline__ void finish_tiles(const clipfs_gemm_args& g, int patc
           for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * g.ldres];
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] += u[r];
+        }
+        if (g.act == 3) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         float* q = g.C + base;
 #pragma unroll

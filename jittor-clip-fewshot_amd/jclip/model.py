@@ -168,7 +168,7 @@ class CLIP(nn.Module):
         """Called when the module tree changes (apply_lora, FlatTrainables) so pointers are re-collected.  The
         engine's user-visible settings (precision mode, text trimming) carry over to the rebuilt engine."""
         if self._engine is not None:
-            self._engine_opts = (self._engine.precision, self._engine.trim_text)
+            self._engine_opts = (self._engine.precision, self._engine.trim_text, self._engine.sparse_backward)
         self._engine = None
 
     @property
@@ -178,7 +178,7 @@ class CLIP(nn.Module):
             self._engine = Engine(self)
             opts = getattr(self, "_engine_opts", None)
             if opts is not None:
-                self._engine.precision, self._engine.trim_text = opts
+                self._engine.precision, self._engine.trim_text, self._engine.sparse_backward = opts
         return self._engine
 
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:

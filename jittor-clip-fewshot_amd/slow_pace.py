@@ -14,8 +14,10 @@
     pre_load_zs       slow_pace.py:1435-1477 cached zero-shot MTA features of the training images
     PromptQueue       README.md:22           queue of learned prompt features blended with the hand-written ones
 
-The MoCo-v3 auxiliary branch (moco_model / Moco_Adapter, slow_pace.py:1677-1680) stays out of scope (SURVEY.md
-section 2 row 17): ``stage2_loss`` is ``sim_ce + L_SCL + lp_ce``, i.e. :1688 without ``loss_aux``.
+    load_moco / Moco_Adapter / pre_load_features_moco / moco_adapter_init / tfm_moco / tfm_clip
+                      slow_pace.py:1208-1219,1237-1274,1151-1168,1542-1552 the MoCo-v3 ResNet-50 auxiliary branch
+                      (frozen extractor on the HIP GEMM, clipfs/resnet.py; ``stage2_loss(..., moco_features=...)`` adds
+                      ``loss_aux`` :1677-1680)
 """
 from __future__ import annotations
 
@@ -298,10 +300,120 @@ class CosineAnnealingLR:
         return self.get_lr()
 
 
+class _LinearFn(torch.autograd.Function):
+    """z = f W^T + c with gradients for W and c (and f): the Moco_Adapter head."""
+
+    @staticmethod
+    def forward(ctx, f, w, c):
+        f = f.contiguous()
+        ctx.save_for_backward(f, w)
+        return ops.gemm_nt(f, w.contiguous(), bias=c.contiguous())
+
+    @staticmethod
+    def backward(ctx, dz):
+        f, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        R, Cn = dz.shape
+        d = f.shape[1]
+        dw = ops.matmul_small(dz, f, Cn, d, R, 1, Cn, d, 1)
+        dc = ops.colsum(dz)
+        df = ops.matmul_small(dz, w.contiguous(), R, d, Cn, Cn, 1, d, 1) if ctx.needs_input_grad[0] else None
+        return df, dw, dc
+
+
+class Moco_Adapter(nn.Module):
+    """slow_pace.py:1208-1219: ``fc = Linear(2048, 403)`` on the frozen ResNet-50 features; trained by ``loss_aux``."""
+
+    def __init__(self, in_dim: int = 2048, n_classes: int = 403, device=None):
+        super().__init__()
+        device = device or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        fc = nn.Linear(in_dim, n_classes)
+        self.fc = fc.to(device) if device is not None else fc
+
+    def forward(self, features: torch.Tensor) -> torch.Tensor:
+        return _LinearFn.apply(features.to(self.fc.weight.device, torch.float32), self.fc.weight, self.fc.bias)
+
+    execute = forward
+
+    def save(self, path: str) -> None:
+        """``moco_adapter.save('test_pkl/moco_adapter.pkl')`` (slow_pace.py:1710)."""
+        from clipfs import module_io
+        module_io.save_module(self, path)
+
+    def load(self, path: str) -> None:
+        from clipfs import module_io
+        module_io.load_module(self, path)
+
+
+CLIP_MEAN_STD = ((0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711))
+MOCO_MEAN_STD = ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+
+
+def _normalizer(mean, std):
+    def tfm(images: torch.Tensor) -> torch.Tensor:
+        """[B, 3, H, W] in [0, 1] -> (x - mean) / std per channel (jittor.transform.ImageNormalize)."""
+        m = torch.tensor(mean, device=images.device, dtype=torch.float32).view(1, 3, 1, 1)
+        s = torch.tensor(std, device=images.device, dtype=torch.float32).view(1, 3, 1, 1)
+        return (images.float() - m) / s
+    return tfm
+
+
+tfm_clip = _normalizer(*CLIP_MEAN_STD)   # slow_pace.py:1273
+tfm_moco = _normalizer(*MOCO_MEAN_STD)   # slow_pace.py:1274
+
+
+def load_moco(pretrain_path, device=None):
+    """slow_pace.py:1237-1271: ``(model, 2048)``; the checkpoint is ``{'state_dict': {'base_encoder.X': array, ...}}``
+    (a pickle of numpy arrays written by the reference's pth_to_pkl.py; read with the inert reader) or such a dict
+    itself.  ``FileNotFoundError`` when the file is missing, like the reference."""
+    import os
+
+    import numpy as np
+
+    from clipfs import resnet, safe_pkl
+    if isinstance(pretrain_path, dict):
+        ck = pretrain_path
+    else:
+        if not os.path.isfile(pretrain_path):
+            print("=> no checkpoint found at '{}'".format(pretrain_path))
+            raise FileNotFoundError(pretrain_path)
+        ck = safe_pkl.load(pretrain_path)
+    sd = ck["state_dict"] if "state_dict" in ck else ck
+    sd = {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v for k, v in sd.items()}
+    sd = resnet.strip_moco_prefix(sd)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    return resnet.MocoResNet50(sd, device), 2048
+
+
+@torch.no_grad()
+def pre_load_features_moco(moco_model, loader):
+    """slow_pace.py:1151-1168: unit-norm ResNet features of every training image and their labels; ``loader`` yields
+    ``(images in [0, 1], target, index)``."""
+    feats, labels = [], []
+    for batch in loader:
+        images, target = batch[0], batch[1]
+        feats.append(moco_model(tfm_moco(torch.as_tensor(images).to(moco_model.device))))
+        labels.append(torch.as_tensor(target).view(-1))
+    f = torch.cat(feats, dim=0)
+    f = ops.l2norm_fwd(f.contiguous())            # mean over ONE augmentation pass (:1155) is the identity
+    return f, torch.cat(labels).to(f.device)
+
+
+@torch.no_grad()
+def moco_adapter_init(moco_adapter: "Moco_Adapter", moco_features: torch.Tensor, moco_labels: torch.Tensor) -> None:
+    """slow_pace.py:1545-1551: ``fc.weight[label] = sum of the unit features of that class`` (few-shot prototype init)."""
+    w = torch.zeros_like(moco_adapter.fc.weight)
+    w.index_add_(0, moco_labels.to(w.device).long(), moco_features.to(w.device, torch.float32))
+    moco_adapter.fc.weight.copy_(w)
+
+
 def stage2_loss(image_features: torch.Tensor, text_features: torch.Tensor, target: torch.Tensor,
                 zs_image_features: torch.Tensor, zs_text_features: torch.Tensor, channel_lp: "Channel_LP",
-                lp_image_features: torch.Tensor, lp_text_features: torch.Tensor):
-    """The stage-2 objective of slow_pace.py:1636-1688 without the MoCo term.
+                lp_image_features: torch.Tensor, lp_text_features: torch.Tensor,
+                moco_adapter: Optional["Moco_Adapter"] = None, moco_features: Optional[torch.Tensor] = None):
+    """The stage-2 objective of slow_pace.py:1636-1688.  With ``moco_adapter`` and ``moco_features`` (= ``moco_model(
+    tfm_moco(images))``, [B, 2048], no grad) the MoCo term ``loss_aux = CE(logit_normalize(moco_adapter(features)),
+    target)`` (:1677-1680) is added as in :1688; without them the objective is ``sim_ce + L_SCL + lp_ce``.
 
     ``image_features`` [B, d] / ``text_features`` [C, d]: the prompted, UN-normalised tower outputs (with grad);
     ``zs_*``: the cached zero-shot features (unit norm, constants; :1650,1654-1655);
@@ -324,9 +436,14 @@ def stage2_loss(image_features: torch.Tensor, text_features: torch.Tensor, targe
     lp_ce = E.cross_entropy_loss(out_lp, tgt_lp)                             # :1669
     sim_ce = E.cross_entropy_loss(cos, target)                               # :1686
     l_scl = loss_scl_logits + loss_scl_text + loss_scl_image                 # :1684
-    loss = sim_ce + l_scl + lp_ce                                            # :1688 minus loss_aux
+    loss = sim_ce + l_scl + lp_ce
     terms = {"sim_ce": sim_ce, "scl_text": loss_scl_text, "scl_image": loss_scl_image, "scl_logits": loss_scl_logits,
              "lp_ce": lp_ce}
+    if moco_adapter is not None and moco_features is not None:
+        out_moco = logit_normalize(moco_adapter(moco_features.detach()))     # :1678-1679
+        loss_aux = E.cross_entropy_loss(out_moco, target)                    # :1680
+        loss = loss + loss_aux                                               # :1688
+        terms["loss_aux"] = loss_aux
     return loss, terms, cos
 
 
@@ -369,8 +486,8 @@ class PromptQueue:
 
 
 class Stage2Trainer:
-    """The loop body of slow_pace.py:1622-1697 (MoCo branch excluded) as one object: prompt ctx + VPT tokens +
-    Channel_LP head are trained (the LoRA adapters stay applied but frozen: :1551-1556 clears ``requires_grad`` on
+    """The loop body of slow_pace.py:1622-1697 as one object: prompt ctx + VPT tokens + Channel_LP head (+ the
+    Moco_Adapter when ``moco_model`` / ``moco_adapter`` are given: ``loss_aux`` :1677-1680, parameters :1584-1586) are trained (the LoRA adapters stay applied but frozen: :1551-1556 clears ``requires_grad`` on
     everything of the CLIP model that is not a VPT parameter), AdamW(weight_decay 1e-2, betas (0.9, 0.999)) with
     ``CosineAnnealingLR(total_epoch, eta_min=1e-6)`` stepped once per iteration (:1590-1591,1696-1697).
 
@@ -381,8 +498,10 @@ class Stage2Trainer:
     def __init__(self, clip_model, prompt_learner: "VLPromptLearner", channel_lp: "Channel_LP",
                  zs_image_features: torch.Tensor, zs_text_features: torch.Tensor,
                  zs_text_feature_sets: Optional[Sequence[torch.Tensor]] = None, lr: float = 2e-4, total_epoch: int = 20,
-                 weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8):
+                 weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8, moco_model=None,
+                 moco_adapter: Optional["Moco_Adapter"] = None):
         self.model, self.prompt_learner, self.head = clip_model, prompt_learner, channel_lp
+        self.moco_model, self.moco_adapter = moco_model, moco_adapter
         self.text_encoder = TextEncoder(clip_model)
         dev = clip_model.device
         self.zs_img = zs_image_features.to(dev, torch.float32)
@@ -393,26 +512,36 @@ class Stage2Trainer:
             clip_model.visual.VPT.requires_grad_(True)
             self.params.append(clip_model.visual.VPT)
         self.params += list(channel_lp.parameters())
+        if moco_adapter is not None:
+            self.params += list(moco_adapter.parameters())
         self.m = [torch.zeros_like(p.data) for p in self.params]
         self.v = [torch.zeros_like(p.data) for p in self.params]
         self.sched = CosineAnnealingLR(lr, total_epoch)
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.t = 0
 
-    def loss(self, images: torch.Tensor, target: torch.Tensor, index: torch.Tensor, template_choice: int = 0):
+    def loss(self, images: torch.Tensor, target: torch.Tensor, index: torch.Tensor, template_choice: int = 0,
+             raw_images: Optional[torch.Tensor] = None):
+        """``images``: CLIP-normalised batch (``tfm_clip(raw)``, :1624); ``raw_images`` in [0, 1] feed the MoCo branch
+        through ``tfm_moco`` (:1677) when it is enabled."""
         m = self.model
         text_features = self.text_encoder(self.prompt_learner())                  # :1626-1629
         image_features = m.encode_image(images)                                   # :1636
         with torch.no_grad():
             lp_img = m.encode_image(images)                                       # :1660-1661 (second forward)
         zs_img = self.zs_img[index.to(self.zs_img.device)]
+        moco_feats = None
+        if self.moco_model is not None and self.moco_adapter is not None:
+            if raw_images is None:
+                raise ValueError("the MoCo branch needs raw_images (in [0, 1]) next to the CLIP-normalised batch")
+            moco_feats = self.moco_model(tfm_moco(raw_images.to(m.device)))           # :1677 (frozen, no grad)
         return stage2_loss(image_features, text_features, target.to(m.device), zs_img, self.zs_txt, self.head, lp_img,
-                           self.zs_sets[template_choice % len(self.zs_sets)])
+                           self.zs_sets[template_choice % len(self.zs_sets)], self.moco_adapter, moco_feats)
 
-    def step(self, images, target, index, template_choice: int = 0):
+    def step(self, images, target, index, template_choice: int = 0, raw_images: Optional[torch.Tensor] = None):
         for p in self.params:
             p.grad = None
-        loss, terms, cos = self.loss(images, target, index, template_choice)
+        loss, terms, cos = self.loss(images, target, index, template_choice, raw_images)
         loss.backward()
         self.t += 1
         for p, mm, vv in zip(self.params, self.m, self.v):

@@ -554,6 +554,42 @@ def stage2_loss(image_features: Tensor, text_features: Tensor, target: Tensor, z
 
 
 # --------------------------------------------------------------------------
+# MoCo-v3 ResNet-50 auxiliary branch  (slow_pace.py:1208-1219,1237-1271,1677-1680)
+# --------------------------------------------------------------------------
+
+
+def resnet50_forward(sd: Dict[str, Tensor], x: Tensor, eps: float = 1e-5) -> Tensor:
+    """jittor.models.resnet.resnet50 (= torchvision ResNet-50 v1.5: Bottleneck with the stride on the 3x3 convolution)
+    with ``fc`` replaced by Identity (slow_pace.py:1269), inference-mode BatchNorm (running statistics; the build's
+    flagged choice, see clipfs/resnet.py): x [B, 3, H, W] normalised images -> [B, 2048] pooled features."""
+    import torch.nn.functional as F
+
+    def bn(t, name):
+        return F.batch_norm(t, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"], sd[name + ".bias"],
+                            False, 0.0, eps)
+
+    y = F.relu(bn(F.conv2d(x, sd["conv1.weight"], None, 2, 3), "bn1"))
+    y = F.max_pool2d(y, 3, 2, 1)
+    for li, nb in enumerate((3, 4, 6, 3)):
+        for bi in range(nb):
+            p = f"layer{li + 1}.{bi}"
+            stride = 2 if (bi == 0 and li > 0) else 1
+            idn = y
+            o = F.relu(bn(F.conv2d(y, sd[p + ".conv1.weight"]), p + ".bn1"))
+            o = F.relu(bn(F.conv2d(o, sd[p + ".conv2.weight"], None, stride, 1), p + ".bn2"))
+            o = bn(F.conv2d(o, sd[p + ".conv3.weight"]), p + ".bn3")
+            if bi == 0:
+                idn = bn(F.conv2d(y, sd[p + ".downsample.0.weight"], None, stride), p + ".downsample.1")
+            y = F.relu(o + idn)
+    return y.mean(dim=(2, 3))
+
+
+def moco_aux_loss(features: Tensor, fc_w: Tensor, fc_b: Tensor, target: Tensor) -> Tensor:
+    """slow_pace.py:1678-1680: CE(logit_normalize(Moco_Adapter(features)), target)."""
+    return jt_cross_entropy(logit_normalize(jt_linear(features, fc_w, fc_b)), target.long())
+
+
+# --------------------------------------------------------------------------
 # MTA  (lora_train_vlp.py:733-811 ; slow_pace.py:1363-1433)
 # --------------------------------------------------------------------------
 

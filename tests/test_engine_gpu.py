@@ -643,3 +643,37 @@ def test_dropout_follows_train_mode_not_grad_mode(dev, monkeypatch):
     model.eval()
     with torch.no_grad():
         assert _err(model.encode_image(img.to(dev)), want_eval) < 2e-5
+
+
+def test_sparse_and_dense_backward_agree(dev, monkeypatch):
+    """The backward that starts from the one row per sequence carrying gradient (clipfs_tower_bwd_sparse: last block's
+    MLP / out-proj input-gradients on batch rows) against the dense backward over a zero-filled tensor: every LoRA, prompt
+    and VPT gradient identical to fp32 rounding, with dropout on and q/k/v/o adapters (o in the last block = the dense
+    fall-back inside the sparse entry point)."""
+    import lora_train_vlp as L
+    from clipfs import synth
+    for params, n_vpt in ((("q", "k", "v"), 0), (("q", "v"), 2), (("q", "k", "v", "o"), 0)):
+        cfg = synth.SMALL
+        sd, model = _build(cfg, dev, n_vpt=n_vpt)
+        args = _args("small", params=params, r=4, p=0.25)
+        _apply(model, cfg, args, synth.synth_lora(cfg, 4, seed=5, params=params), monkeypatch)
+        L.mark_only_lora_as_trainable(model)
+        if n_vpt:
+            model.visual.VPT.requires_grad_(True)
+        model.train()
+        ctx_param = torch.nn.Parameter(sd["token_embedding.weight"][[5, 6, 7, 8]].clone().to(dev))
+        tr = L.LoRATrainer(model, prompt_ctx=ctx_param)
+        B, Cn = 6, 9
+        img = synth.synth_images(B, cfg.image_resolution, seed=3).to(dev)
+        cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=4, max_len=12).to(dev)
+        tgt = synth.synth_labels(B, Cn, seed=2).to(dev)
+        got = {}
+        for sparse in (True, False):
+            model.engine.sparse_backward = sparse
+            model.engine.step = 0  # same dropout seed for both passes
+            tr.flat.zero_grad()
+            tr.forward_backward(img, cap, tgt)
+            got[sparse] = tr.flat.grads.clone()
+        scale = got[False].abs().max().item()
+        assert scale > 1e-4
+        assert (got[True] - got[False]).abs().max().item() < 2e-6 * scale + 1e-9, params

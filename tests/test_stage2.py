@@ -118,6 +118,20 @@ def test_stage2_loss_matches_oracle_with_gradients():
     assert close(img.grad, img64.grad, 2e-4) and close(txt.grad, txt64.grad, 2e-4)
     assert close(head.scale1.grad, lp64[0].grad, 2e-4) and close(head.bias1.grad, lp64[1].grad, 2e-4)
     assert close(head.fc.weight.grad, lp64[2].grad, 2e-4) and close(head.fc.bias.grad, lp64[3].grad, 2e-4)
+    # with the MoCo branch: loss = the above + loss_aux (slow_pace.py:1677-1680,1688), adapter gradients from loss_aux only
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(16, 96, generator=g, dtype=torch.float64)
+    ad = S.Moco_Adapter(96, 11, device=dev)
+    ow = ad.fc.weight.detach().double().cpu().requires_grad_()
+    ob = ad.fc.bias.detach().double().cpu().requires_grad_()
+    aux = O.moco_aux_loss(feats, ow, ob, x["target"])
+    aux.backward()
+    loss2, terms2, _ = S.stage2_loss(D(x["img"]), D(x["txt"]), x["target"].to(dev), D(x["zs_img"]), D(x["zs_txt"]), head,
+                                     D(x["lp_img"]), D(x["lp_txt"]), ad, D(feats))
+    loss2.backward()
+    assert abs(terms2["loss_aux"].item() - aux.item()) < 2e-5 * max(1.0, abs(aux.item()))
+    assert abs(loss2.item() - (ref.item() + aux.item())) < 3e-5 * abs(ref.item() + aux.item())
+    assert close(ad.fc.weight.grad, ow.grad, 2e-4) and close(ad.fc.bias.grad, ob.grad, 2e-4)
 
 
 @pytest.mark.gpu
