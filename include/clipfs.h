@@ -226,6 +226,17 @@ int clipfs_gather_seq_rows(const float* src, size_t ld, const int32_t* idx, floa
                            void* stream);
 int clipfs_add_seq_rows(const float* src, const int32_t* idx, float* dx, int n, int seq, int width, void* stream);
 
+/* --------------------------------------------------------- BPE tokenizer --
+ * Native merge loop of the CLIP byte-pair encoder (jclip/simple_tokenizer.py:88-129; host code, no GPU work).
+ * create: `merges` = the merges text after its header line, one "left right" per line; returns an opaque handle or
+ * NULL.  encode: word w = UTF-8 bytes [offsets[w], offsets[w+1]) of `words` (already cleaned, lower-cased and split by
+ * the caller); writes each word's vocabulary ids consecutively into ids (capacity cap) and their number into
+ * counts[w]; returns the total or -1. */
+void* clipfs_bpe_create(const char* merges, size_t n_bytes, int n_merges);
+void clipfs_bpe_destroy(void* handle);
+long clipfs_bpe_encode(const void* handle, const uint8_t* words, const int32_t* offsets, int n_words, int32_t* ids,
+                       int32_t* counts, long cap);
+
 /* ------------------------------------------------- MoCo ResNet-50 branch --
  * Data movement of the frozen ResNet-50 feature extractor (slow_pace.py:1237-1271,1677-1680; forward only, NHWC
  * activations; convolutions run as clipfs_gemm_nt with BatchNorm folded into weights / bias and ReLU = act 3):

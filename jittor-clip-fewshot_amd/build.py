@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "clipfs", "libclipfs_hip.so")
-SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "gemm_f16.hip", "norm.hip", "attention.hip", "attention_f16.hip", "attention_mfma.hip", "attention_mfma16.hip", "lora.hip", "lora_mfma.hip", "elem.hip", "mta.hip", "views.hip", "resnet.hip", "tower.hip"]
+SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "gemm_f16.hip", "norm.hip", "attention.hip", "attention_f16.hip", "attention_mfma.hip", "attention_mfma16.hip", "lora.hip", "lora_mfma.hip", "elem.hip", "mta.hip", "views.hip", "resnet.hip", "bpe.hip", "tower.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-Wall",
          "-Wno-unused-function", "-ffp-contract=off"]

@@ -115,6 +115,9 @@ SIGNATURES = {
     "clipfs_mta_work_floats": (_sz, [_i, _i, _i, _i]),
     "clipfs_mta": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_tta_views": (_i, [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p]),
+    "clipfs_bpe_create": (C.c_void_p, [C.c_char_p, _sz, _i]),
+    "clipfs_bpe_destroy": (None, [C.c_void_p]),
+    "clipfs_bpe_encode": (C.c_long, [C.c_void_p, _p, _p, _i, _p, _p, C.c_long]),
     "clipfs_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "clipfs_im2col_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "clipfs_maxpool3x3s2_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -90,9 +90,56 @@ def whitespace_clean(text: str) -> str:
     return _WS.sub(" ", text).strip()
 
 
+class _NativeBpe:
+    """The merge loop in native code (csrc/bpe.hip, C ABI ``clipfs_bpe_*``): words in, vocabulary ids out."""
+
+    def __init__(self, merges: List[Tuple[str, str]]):
+        import ctypes as C
+
+        import numpy as np
+        from clipfs import _lib
+        self._np, self._C = np, C
+        self._lib = _lib.load()
+        text = "\n".join(a + " " + b for a, b in merges).encode("utf-8") + b"\n"
+        self._h = self._lib.clipfs_bpe_create(text, len(text), len(merges))
+        if not self._h:
+            raise RuntimeError("clipfs_bpe_create failed: " + self._lib.clipfs_last_error().decode("utf-8", "replace"))
+
+    def encode_words(self, words: List[bytes]) -> List[List[int]]:
+        np = self._np
+        if not words:
+            return []
+        blob = np.frombuffer(b"".join(words), dtype=np.uint8) if any(words) else np.zeros(1, np.uint8)
+        offs = np.zeros(len(words) + 1, np.int32)
+        np.cumsum([len(w) for w in words], out=offs[1:])
+        ids = np.empty(max(int(offs[-1]), 1), np.int32)
+        counts = np.empty(len(words), np.int32)
+        n = self._lib.clipfs_bpe_encode(self._h, blob.ctypes.data, offs.ctypes.data, len(words), ids.ctypes.data,
+                                        counts.ctypes.data, ids.size)
+        if n < 0:
+            raise RuntimeError("clipfs_bpe_encode failed: " + self._lib.clipfs_last_error().decode("utf-8", "replace"))
+        out, pos = [], 0
+        for c in counts.tolist():
+            out.append(ids[pos:pos + c].tolist())
+            pos += c
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.clipfs_bpe_destroy(self._h)
+        except Exception:
+            pass
+
+
 class SimpleTokenizer:
-    def __init__(self, bpe_path: str = None):
+    """``native=True`` (default): the merge loop runs in the library's C++ BPE core; ``native=False`` keeps the pure
+    Python loop below (the cross-check of tests/test_tokenizer.py).  Both produce the same ids."""
+
+    def __init__(self, bpe_path: str = None, native: bool = True):
         merges = _read_merges(bpe_path or default_bpe())
+        self._native = _NativeBpe(merges) if native else None
+        self._id_cache: Dict[str, List[int]] = {}
         b2u = bytes_to_unicode()
         self.byte_encoder = b2u
         self.byte_decoder = {u: b for b, u in b2u.items()}
@@ -144,7 +191,17 @@ class SimpleTokenizer:
         text = whitespace_clean(basic_clean(text)).lower()
         ids: List[int] = []
         b2u, enc = self.byte_encoder, self.encoder
-        for piece in self.pat.findall(text):
+        pieces = self.pat.findall(text)
+        if self._native is not None:
+            cache = self._id_cache
+            todo = [p for p in dict.fromkeys(pieces) if p not in cache and p not in (SOT, EOT)]
+            if todo:
+                for p, got in zip(todo, self._native.encode_words([p.encode("utf-8") for p in todo])):
+                    cache[p] = got
+            for p in pieces:
+                ids.extend([enc[p]] if p in (SOT, EOT) else cache[p])
+            return ids
+        for piece in pieces:
             mapped = "".join(b2u[b] for b in piece.encode("utf-8"))
             ids.extend(enc[s] for s in self.bpe(mapped).split(" "))
         return ids
