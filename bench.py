@@ -138,7 +138,9 @@ def build_trainer(dev, args, model_name=None, precision=None):
                     m_.w_lora_A.copy_(torch.from_numpy(lw[f"layer_{i}"][names[p_]]["w_lora_A"]))
                     m_.w_lora_B.copy_(torch.from_numpy(lw[f"layer_{i}"][names[p_]]["w_lora_B"]))
     else:
-        L.load_lora(largs, layers, os.path.join(ROOT, "tests", "golden", "lora_weights.pkl"))
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):  # load_lora prints like the reference; stdout carries ONE JSON line
+            L.load_lora(largs, layers, os.path.join(ROOT, "tests", "golden", "lora_weights.pkl"))
     L.mark_only_lora_as_trainable(model)
     # 4 prompt tokens initialised from the embeddings of "a photo of a" (slow_pace.py:124-131)
     ids = torch.tensor([320, 1125, 539, 320], device=dev)
