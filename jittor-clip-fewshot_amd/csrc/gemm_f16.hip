@@ -48,6 +48,170 @@ struct F16Params {
   int n_blocks_n;
 };
 
+// What both f16 kernels do after their K loop for the TM x TN accumulator tiles of one wave whose first row / column
+// are mw / nw: the rank-r LoRA up-projection as ONE more MFMA K-step, then the fused epilogue.
+template <int TM, int TN>
+__device__ __forceinline__ void f16_finish(const F16Params& p, f32x16 (&acc)[TM][TN], int mw, int nw, int n0, bool full_tile,
+                                           int lane) {
+  const clipfs_gemm_args& g = p.a;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int Mend = p.m_end, N = g.N;
+  // ---- LoRA up-projection: one more K-step of 16 (rank zero-padded), operands converted in registers ----------
+  if (g.lora_t) {
+    const int r = g.lora_r;
+    const int seg = n0 / g.lora_seg_width;  // the host guarantees a block tile lies inside one segment
+    f16x8 av[TM], bv[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int m = min(mw + t * 32 + fr, Mend - 1);
+      const float* tp = g.lora_t + (size_t)m * (g.lora_nseg * r) + seg * r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * fh + j;
+        av[t][j] = (_Float16)(tp[min(k, r - 1)] * (k < r ? 1.f : 0.f));
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int n = min(nw + t * 32 + fr, N - 1);
+      const float* lb = g.lora_b + (size_t)n * r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * fh + j;
+        bv[t][j] = (_Float16)(lb[min(k, r - 1)] * (k < r ? g.lora_scale : 0.f));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane owns column n of each 32x32 tile and 16 of its rows (4 groups of 4 consecutive) ---------
+  // Row offsets inside a 32x32 tile: (r & 3) + 8 (r >> 2) + 4 fh.  Every option is a wave-uniform branch around a
+  // 16-element pass so the common cases stay straight-line.
+  const int ldc = g.ldc;
+  if (full_tile) {  // whole tile inside the problem: no predicates, loads of a pass issued together
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + j * 32 + fr;
+      const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = mw + i * 32 + 4 * fh;
+        const size_t base = (size_t)mb * ldc + n;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
+        if (g.act == 1) {
+          if (g.aux_out) {
+            if (g.aux_f16) {
+              _Float16* q = reinterpret_cast<_Float16*>(g.aux_out) + base;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
+            } else {
+              float* q = g.aux_out + base;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = quick_gelu_fast(v[r]);
+        } else if (g.act == 2) {
+          float u[16];
+          if (g.aux_f16) {
+            const _Float16* q = reinterpret_cast<const _Float16*>(g.aux_in) + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = (float)q[((r & 3) + 8 * (r >> 2)) * ldc];
+          } else {
+            const float* q = g.aux_in + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * ldc];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad_fast(u[r]);
+        }
+        if (g.residual) {
+          const float* q = g.residual + (size_t)mb * g.ldres + n;
+          float u[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * g.ldres];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += u[r];
+        }
+        if (g.C) {
+          float* q = g.C + base;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+        }
+        if (p.C16) {
+          _Float16* q = p.C16 + base;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = nw + j * 32 + fr;
+    const bool n_ok = n < N;
+    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = mw + i * 32 + 4 * fh;
+      const size_t base = (size_t)mb * ldc + n;
+      int ok = 0;  // bit r set: element r is inside the problem
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ok |= (n_ok && mb + (r & 3) + 8 * (r >> 2) < Mend) ? (1 << r) : 0;
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
+      if (g.act == 1) {
+        if (g.aux_out) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (ok >> r & 1) {
+              const size_t o = base + (size_t)((r & 3) + 8 * (r >> 2)) * ldc;
+              if (g.aux_f16)
+                reinterpret_cast<_Float16*>(g.aux_out)[o] = (_Float16)v[r];
+              else
+                g.aux_out[o] = v[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = quick_gelu_fast(v[r]);
+      } else if (g.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) {
+            const size_t o = base + (size_t)((r & 3) + 8 * (r >> 2)) * ldc;
+            v[r] *= quick_gelu_grad_fast(g.aux_f16 ? (float)reinterpret_cast<const _Float16*>(g.aux_in)[o] : g.aux_in[o]);
+          }
+      }
+      if (g.residual) {
+        const float* q = g.residual + (size_t)mb * g.ldres + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) v[r] += q[((r & 3) + 8 * (r >> 2)) * g.ldres];
+      }
+      if (g.C) {
+        float* q = g.C + base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+      }
+      if (p.C16) {
+        _Float16* q = p.C16 + base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
+      }
+    }
+  }
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -163,160 +327,161 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
     nxt = nxt == 2 ? 0 : nxt + 1;
   }
 
-  // ---- LoRA up-projection: one more K-step of 16 (rank zero-padded), operands converted in registers ----------
-  if (g.lora_t) {
-    const int r = g.lora_r;
-    const int seg = n0 / g.lora_seg_width;  // the host guarantees lora_seg_width % BN == 0
-    f16x8 av[TM], bv[TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      const int m = min(m0 + wm * (BM / 2) + t * 32 + fr, Mend - 1);
-      const float* tp = g.lora_t + (size_t)m * (g.lora_nseg * r) + seg * r;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = 8 * fh + j;
-        av[t][j] = (_Float16)(tp[min(k, r - 1)] * (k < r ? 1.f : 0.f));
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      const int n = min(n0 + wn * (BN / 2) + t * 32 + fr, N - 1);
-      const float* lb = g.lora_b + (size_t)n * r;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = 8 * fh + j;
-        bv[t][j] = (_Float16)(lb[min(k, r - 1)] * (k < r ? g.lora_scale : 0.f));
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
-  }
+  f16_finish<TM, TN>(p, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), n0, m0 + BM <= Mend && n0 + BN <= N, lane);
+}
 
-  // ---- epilogue: lane owns column n of each 32x32 tile and 16 of its rows (4 groups of 4 consecutive) ---------
-  // Row offsets inside a 32x32 tile: (r & 3) + 8 (r >> 2) + 4 fh.  Every option is a wave-uniform branch around a
-  // 16-element pass so the common cases stay straight-line.
-  const int ldc = g.ldc;
-  if (m0 + BM <= Mend && n0 + BN <= N) {  // whole tile inside the problem: no predicates, loads of a pass issued together
+// ---- 256 x 256 "ping-pong" kernel ---------------------------------------------------------------------------------
+// The kernel above tops out where every two-barrier-per-K-step structure does (cdna_hip_programming.md section 5, "the
+// step-3 structure's ceiling"): the two workgroups of a CU drift into the same phase, each wave's MFMAs wait for its
+// own LDS reads, and the LDS-DMA is drained to vmcnt(0)-ish depth at every barrier.  This one follows the guide's
+// recipe for getting past it -- ONE workgroup per CU whose prefetch stays in flight across barriers, counted vmcnt, raw
+// barriers, and the two waves of every SIMD deliberately out of phase:
+//   * block tile 256 x 256 x 32, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 (the same 128 accumulators per lane);
+//     a third less LDS-DMA per MFMA than 256 x 128;
+//   * LDS ring of FOUR stages (4 x 32 KiB = 128 KiB), LDS-DMA issued THREE K-steps ahead (~3 x 1024 cycles: an HBM
+//     miss lands in time), retired with `s_waitcnt vmcnt(8)` -- two younger stages stay in flight;
+//   * per K-step every wave runs LOADS (issue the DMA of step p+3, read ALL fragments of step p, retire its DMA of
+//     step p+1, lgkmcnt(0)) | barrier | 16 MFMAs at raised priority | barrier.  Wave group 1 (the second wave of each
+//     SIMD) executes one extra barrier up front, so it is permanently one barrier behind: while group 0 issues MFMAs,
+//     group 1 is in LOADS, and vice versa -- the matrix pipe always has a wave whose operands are already in
+//     registers.  Group 0 executes the matching extra barrier at the end.
+// Hazards (global barrier numbers; group 0: A_p = 2p+1, B_p = 2p+2; group 1: A_p = 2p+2, B_p = 2p+3):
+//   RAW  stage p+1 is read in LOADS_{p+1}.  Every wave retires ITS share of stage p+1 (vmcnt) inside LOADS_p, i.e.
+//        before its A_p <= #2p+2; group 0 reads after B_p = #2p+2, group 1 after #2p+3.
+//   WAR  ring slot (p+3) % 4 = (p-1) % 4 is overwritten by DMA issued in LOADS_p, i.e. after B_{p-1} >= #2p; all reads
+//        of stage p-1 were complete (lgkmcnt(0)) before the reader's A_{p-1} <= #2p.
+__global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int BM = 256, BN = 256, TM = 4, TN = 2;  // four LDS stages
+  constexpr int PLANE = 256 * 64;     // bytes of one operand plane of a stage
+  constexpr int STAGE = 2 * PLANE;    // 32 KiB
+  constexpr int PER_STAGE = 4;        // LDS-DMA instructions per wave per stage (2 for A, 2 for B)
+
+  const clipfs_gemm_args& g = p.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm is also the ping-pong group: waves 0-3 / 4-7 = first / second wave of a SIMD
+  const int Mend = p.m_end, N = g.N, K = g.K;
+
+  const int tile = xcd_contiguous_unit();
+  constexpr int GM = 4;
+  const int nbn = p.n_blocks_n;
+  const int grp = tile / (GM * nbn);
+  const int rem = tile - grp * (GM * nbn);
+  const int mb_total = (Mend - p.m_begin + BM - 1) / BM;
+  const int gmm = min(GM, mb_total - grp * GM);
+  const int m0 = p.m_begin + (grp * GM + rem % gmm) * BM;
+  const int n0 = (rem / gmm) * BN;
+
+  // staging: instruction i of an operand covers rows 16 (wave + 8 i) .. + 15, 64 B each
+  const char* a_src[2];
+  const char* b_src[2];
+  int st_off[2];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 32 + fr;
-      const float bias = g.bias ? g.bias[n] : 0.f;
+  for (int i = 0; i < 2; ++i) {
+    const int r0 = 16 * (wave + 8 * i), row = r0 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+    a_src[i] = reinterpret_cast<const char*>(p.A16 + (size_t)min(m0 + row, Mend - 1) * g.lda + 8 * c);
+    b_src[i] = reinterpret_cast<const char*>(p.B16 + (size_t)min(n0 + row, N - 1) * g.ldb + 8 * c);
+    st_off[i] = r0 * 64;
+  }
+  const int fr = lane & 31, fh = lane >> 5;
+  int a_frag[TM], b_frag[TN], a_swz[TM], b_swz[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
-        const size_t base = (size_t)mb * ldc + n;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
-        if (g.act == 1) {
-          if (g.aux_out) {
-            if (g.aux_f16) {
-              _Float16* q = reinterpret_cast<_Float16*>(g.aux_out) + base;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
-            } else {
-              float* q = g.aux_out + base;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = quick_gelu_fast(v[r]);
-        } else if (g.act == 2) {
-          float u[16];
-          if (g.aux_f16) {
-            const _Float16* q = reinterpret_cast<const _Float16*>(g.aux_in) + base;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) u[r] = (float)q[((r & 3) + 8 * (r >> 2)) * ldc];
-          } else {
-            const float* q = g.aux_in + base;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * ldc];
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad_fast(u[r]);
-        }
-        if (g.residual) {
-          const float* q = g.residual + (size_t)mb * g.ldres + n;
-          float u[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * g.ldres];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += u[r];
-        }
-        if (g.C) {
-          float* q = g.C + base;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
-        }
-        if (p.C16) {
-          _Float16* q = p.C16 + base;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
-        }
-      }
-    }
-    return;
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * 128 + t * 32 + fr;
+    a_frag[t] = row * 64;
+    a_swz[t] = (row >> 2) & 3;
   }
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / 2) + j * 32 + fr;
-    const bool n_ok = n < N;
-    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
-      const size_t base = (size_t)mb * ldc + n;
-      int ok = 0;  // bit r set: element r is inside the problem
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ok |= (n_ok && mb + (r & 3) + 8 * (r >> 2) < Mend) ? (1 << r) : 0;
-      float v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = g.alpha * acc[i][j][r] + bias;
-      if (g.act == 1) {
-        if (g.aux_out) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (ok >> r & 1) {
-              const size_t o = base + (size_t)((r & 3) + 8 * (r >> 2)) * ldc;
-              if (g.aux_f16)
-                reinterpret_cast<_Float16*>(g.aux_out)[o] = (_Float16)v[r];
-              else
-                g.aux_out[o] = v[r];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = quick_gelu_fast(v[r]);
-      } else if (g.act == 2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (ok >> r & 1) {
-            const size_t o = base + (size_t)((r & 3) + 8 * (r >> 2)) * ldc;
-            v[r] *= quick_gelu_grad_fast(g.aux_f16 ? (float)reinterpret_cast<const _Float16*>(g.aux_in)[o] : g.aux_in[o]);
-          }
-      }
-      if (g.residual) {
-        const float* q = g.residual + (size_t)mb * g.ldres + n;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (ok >> r & 1) v[r] += q[((r & 3) + 8 * (r >> 2)) * g.ldres];
-      }
-      if (g.C) {
-        float* q = g.C + base;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
-      }
-      if (p.C16) {
-        _Float16* q = p.C16 + base;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (ok >> r & 1) q[((r & 3) + 8 * (r >> 2)) * ldc] = (_Float16)v[r];
-      }
-    }
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * 64 + t * 32 + fr;
+    b_frag[t] = PLANE + row * 64;
+    b_swz[t] = (row >> 2) & 3;
   }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto stage_in = [&](int kt, int slot) __attribute__((always_inline)) {
+    char* s = smem_raw + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(a_src[i] + (size_t)kt * (BK * 2), s + st_off[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(b_src[i] + (size_t)kt * (BK * 2), s + PLANE + st_off[i]);
+  };
+
+  const int nk = K / BK;
+  // prologue: three stages in flight, stage 0 landed and published
+  stage_in(0, 0);
+  if (nk > 1) stage_in(1, 1);
+  if (nk > 2) stage_in(2, 2);
+  if (nk > 2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STAGE) : "memory");
+  else if (nk > 1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // #0: stage 0 readable by everyone
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();    // group 1 falls one barrier behind (pairs with group 0's A_0)
+
+  int slot = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- LOADS ----
+    if (kt + 3 < nk) stage_in(kt + 3, (slot + 3) & 3);  // into the slot step kt-1 used: released at #2 kt
+    const char* s = smem_raw + slot * STAGE;
+    f16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bv[kb][t] = *reinterpret_cast<const f16x8*>(s + b_frag[t] + (((2 * kb + fh) ^ b_swz[t]) << 4));
+#pragma unroll
+      for (int t = 0; t < TM; ++t) av[kb][t] = *reinterpret_cast<const f16x8*>(s + a_frag[t] + (((2 * kb + fh) ^ a_swz[t]) << 4));
+    }
+    // retire this wave's share of step kt+1; stages kt+2 and kt+3 (where issued) stay in flight
+    const int younger = min(2, nk - 2 - kt);  // stages issued after kt+1
+    if (younger >= 2)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PER_STAGE) : "memory");
+    else if (younger == 1)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER_STAGE) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // A_kt
+    asm volatile("" ::: "memory");
+    // ---- MFMA ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kb][i], bv[kb][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();  // B_kt
+    asm volatile("" ::: "memory");
+    slot = (slot + 1) & 3;
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
+  f16_finish<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, m0 + BM <= Mend && n0 + BN <= N, lane);
+}
+
+static int launch_f16_pp(F16Params& p, hipStream_t stream) {
+  p.n_blocks_n = (p.a.N + 255) / 256;
+  const int mb = (p.m_end - p.m_begin + 255) / 256;
+  const size_t lds = 4 * (size_t)(2 * 256 * 64);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_f16_pp_kernel, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  return launch_status();
 }
 
 template <int BM, int BN>
@@ -334,6 +499,34 @@ static int launch_f16(F16Params& p, hipStream_t stream) {
   return launch_status();
 }
 
+// rows [p.m_begin, p.m_end) on the 4-wave kernels: 256 x 128 tiles on the rows that fill whole rounds of 512 workgroup
+// slots (2 per CU), the leftover rows in 64-row tiles behind them; small problems on small tiles
+static int dispatch_rows_4wave(F16Params& p, int tile_cfg, hipStream_t stream) {
+  const clipfs_gemm_args& a = p.a;
+  const int M = p.m_end - p.m_begin;
+  const bool lora_ok_256 = !a.lora_t || a.lora_seg_width % 128 == 0;
+  if (tile_cfg == 2) return launch_f16<64, 128>(p, stream);
+  if (tile_cfg == 1) return launch_f16<128, 128>(p, stream);
+  if (tile_cfg == 3 && lora_ok_256) return launch_f16<256, 128>(p, stream);
+  const int nbn = (a.N + 127) / 128;
+  if ((long)((M + 255) / 256) * nbn < 512) {
+    return ((long)((M + 127) / 128) * nbn >= 512) ? launch_f16<128, 128>(p, stream) : launch_f16<64, 128>(p, stream);
+  }
+  const int mb = (M + 255) / 256;
+  const long tiles = (long)mb * nbn;
+  const long over = tiles % 512;  // tiles beyond the last full round of 512 slots
+  int peel_blocks = 0;
+  if (tiles > 512 && over > 0 && over * 8 <= 512) peel_blocks = (int)((over + nbn - 1) / nbn);
+  const int begin = p.m_begin, end = p.m_end;
+  const int split = begin + (mb - peel_blocks) * 256;
+  if (peel_blocks == 0 || split >= end || split <= begin) return launch_f16<256, 128>(p, stream);
+  p.m_end = split;
+  CLIPFS_CHECK((launch_f16<256, 128>(p, stream)));
+  p.m_begin = split;
+  p.m_end = end;
+  return launch_f16<64, 128>(p, stream);
+}
+
 // called from clipfs_gemm_nt when args->A_f16 is set
 int gemm_f16_dispatch(const clipfs_gemm_args& a, hipStream_t stream) {
   F16Params p;
@@ -343,31 +536,40 @@ int gemm_f16_dispatch(const clipfs_gemm_args& a, hipStream_t stream) {
   p.C16 = reinterpret_cast<_Float16*>(a.C_f16);
   p.m_begin = 0;
   p.m_end = a.M;
-  static const int tile_cfg = getenv("CLIPFS_F16_TILE") ? atoi(getenv("CLIPFS_F16_TILE")) : 0;  // tuning aid
-  const bool lora_ok_256 = !a.lora_t || a.lora_seg_width % 128 == 0;
-  if (tile_cfg == 2) return launch_f16<64, 128>(p, stream);
-  if (tile_cfg == 1) return launch_f16<128, 128>(p, stream);
-  if (tile_cfg == 3 && lora_ok_256) return launch_f16<256, 128>(p, stream);
-  const int nbn = (a.N + 127) / 128;
-  // Few tiles: small tiles keep the CUs busy.  Otherwise 256x128 tiles on the rows that fill whole rounds of
-  // 512 workgroup slots (2 per CU), and the leftover rows in 64-row tiles behind them.
-  if ((long)((a.M + 255) / 256) * nbn < 512) {
-    return ((long)((a.M + 127) / 128) * nbn >= 512) ? launch_f16<128, 128>(p, stream) : launch_f16<64, 128>(p, stream);
+  // tuning aid CLIPFS_F16_TILE: 1 / 2 / 3 force the 128x128 / 64x128 / 256x128 4-wave kernel, 4 forces the 256x256
+  // ping-pong kernel on every row, 5 disables it
+  static const int tile_cfg = getenv("CLIPFS_F16_TILE") ? atoi(getenv("CLIPFS_F16_TILE")) : 0;
+  const bool lora_ok_pp = !a.lora_t || a.lora_seg_width % 256 == 0;
+  if (tile_cfg == 4 && lora_ok_pp) return launch_f16_pp(p, stream);
+  if (tile_cfg >= 1 && tile_cfg <= 3) return dispatch_rows_4wave(p, tile_cfg, stream);
+  // 256 x 256 ping-pong tiles (one workgroup per CU) on the rows that fill whole rounds over the CUs -- a last round is
+  // accepted when it is at least 80 % full -- and the 4-wave kernels on what is left
+  if (tile_cfg != 5 && lora_ok_pp && a.K >= 4 * BK) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0, v = 0;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+             v > 0) ? v : 256;
+    }
+    const int nbn = (a.N + 255) / 256;
+    const int mb = a.M / 256;  // whole 256-row blocks
+    long tiles = (long)mb * nbn;
+    int use_mb = mb;
+    if (tiles >= cus) {
+      const long rem = tiles % cus;
+      if (rem != 0 && rem * 5 < (long)cus * 4) use_mb = (int)((tiles - rem) / nbn);
+    } else if (tiles * 5 < (long)cus * 4) {
+      use_mb = 0;
+    }
+    if (use_mb > 0 && (long)use_mb * 256 * 5 >= (long)a.M * 3) {
+      p.m_end = use_mb * 256;
+      CLIPFS_CHECK(launch_f16_pp(p, stream));
+      if (p.m_end >= a.M) return CLIPFS_OK;
+      p.m_begin = p.m_end;
+      p.m_end = a.M;
+    }
   }
-  const int mb = (a.M + 255) / 256;
-  const long tiles = (long)mb * nbn;
-  const long over = tiles % 512;  // tiles beyond the last full round of 512 slots
-  int peel_blocks = 0;
-  if (tiles > 512 && over > 0 && over * 8 <= 512) peel_blocks = (int)((over + nbn - 1) / nbn);
-  p.m_end = (mb - peel_blocks) * 256;
-  if (peel_blocks == 0 || p.m_end >= a.M || p.m_end <= 0) {
-    p.m_end = a.M;
-    return launch_f16<256, 128>(p, stream);
-  }
-  CLIPFS_CHECK((launch_f16<256, 128>(p, stream)));
-  p.m_begin = p.m_end;
-  p.m_end = a.M;
-  return launch_f16<64, 128>(p, stream);
+  return dispatch_rows_4wave(p, 0, stream);
 }
 
 }  // namespace clipfs
