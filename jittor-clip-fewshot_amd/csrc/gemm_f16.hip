@@ -15,6 +15,7 @@
 // gemm_f16_dispatch -- cuts M so that the big launch is an exact number of rounds over the CUs).
 #include "gemm_common.h"
 
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace clipfs {
@@ -46,13 +47,13 @@ struct F16Params {
   int m_begin;      // first row of this launch (rows [m_begin, m_end) of the problem)
   int m_end;
   int n_blocks_n;
+  int row_major_epilogue;  // 256 x 256 kernel: epilogue through LDS with 8 / 16-byte row accesses (needs 4-column alignment)
 };
 
 // What both f16 kernels do after their K loop for the TM x TN accumulator tiles of one wave whose first row / column
 // are mw / nw: the rank-r LoRA up-projection as ONE more MFMA K-step, then the fused epilogue.
 template <int TM, int TN>
-__device__ __forceinline__ void f16_finish(const F16Params& p, f32x16 (&acc)[TM][TN], int mw, int nw, int n0, bool full_tile,
-                                           int lane) {
+__device__ __forceinline__ void f16_lora_step(const F16Params& p, f32x16 (&acc)[TM][TN], int mw, int nw, int n0, int lane) {
   const clipfs_gemm_args& g = p.a;
   const int fr = lane & 31, fh = lane >> 5;
   const int Mend = p.m_end, N = g.N;
@@ -86,6 +87,15 @@ __device__ __forceinline__ void f16_finish(const F16Params& p, f32x16 (&acc)[TM]
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
   }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void f16_finish(const F16Params& p, f32x16 (&acc)[TM][TN], int mw, int nw, int n0, bool full_tile,
+                                           int lane) {
+  const clipfs_gemm_args& g = p.a;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int Mend = p.m_end, N = g.N;
+  f16_lora_step<TM, TN>(p, acc, mw, nw, n0, lane);
 
   // ---- epilogue: lane owns column n of each 32x32 tile and 16 of its rows (4 groups of 4 consecutive) ---------
   // Row offsets inside a 32x32 tile: (r & 3) + 8 (r >> 2) + 4 fh.  Every option is a wave-uniform branch around a
@@ -330,6 +340,74 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
   f16_finish<TM, TN>(p, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), n0, m0 + BM <= Mend && n0 + BN <= N, lane);
 }
 
+// Row-major epilogue of the 256 x 256 kernel.  The MFMA result layout gives a lane ONE column and 16 rows of each
+// 32 x 32 tile, so a register-side epilogue moves 2 - 4 bytes per lane and instruction (128 values x up to four tensors
+// per lane: at K = 1024 it took longer than the K loop).  Here the raw accumulators of 128 tile rows at a time go
+// through the LDS ring (128 rows x 256 columns x 4 B = its 128 KiB exactly) and all 512 threads then walk the half tile
+// row-major, 4 columns per thread: bias, saved pre-activation, residual, fp32 C and f16 C16 are all 8 / 16-byte accesses
+// of whole rows (a wave covers one 1 KiB row segment per instruction).
+__device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, f32x16 (&acc)[4][2], float* lds, int m0, int n0, int wm, int wn,
+                                                 int tid) {
+  const clipfs_gemm_args& g = p.a;
+  const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  const int Mend = p.m_end, N = g.N, ldc = g.ldc;
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // the ring (or the previous half) is no longer read
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            lds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 256 + wn * 64 + j * 32 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+      const int q = tid + 512 * k;
+      const int row = q >> 6, c4 = q & 63;
+      const int m = m0 + half * 128 + row, n = n0 + 4 * c4;
+      if (m >= Mend || n >= N) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * 256 + 4 * c4);
+      if (g.bias) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+        v = g.alpha * v + b4;
+      } else {
+        v = g.alpha * v;
+      }
+      const size_t o = (size_t)m * ldc + n;
+      if (g.act == 1) {
+        if (g.aux_out) {
+          if (g.aux_f16)
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(g.aux_out) + o) =
+                f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+          else
+            *reinterpret_cast<f32x4*>(g.aux_out + o) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_fast(v[e]);
+      } else if (g.act == 2) {
+        f32x4 u;
+        if (g.aux_f16) {
+          const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(g.aux_in) + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = (float)h[e];
+        } else {
+          u = *reinterpret_cast<const f32x4*>(g.aux_in + o);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_fast(u[e]);
+      }
+      if (g.residual) v += *reinterpret_cast<const f32x4*>(g.residual + (size_t)m * g.ldres + n);
+      if (g.C) *reinterpret_cast<f32x4*>(g.C + o) = v;
+      if (p.C16) *reinterpret_cast<f16x4*>(p.C16 + o) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+  }
+}
+
 // ---- 256 x 256 "ping-pong" kernel ---------------------------------------------------------------------------------
 // The kernel above tops out where every two-barrier-per-K-step structure does (cdna_hip_programming.md section 5, "the
 // step-3 structure's ceiling"): the two workgroups of a CU drift into the same phase, each wave's MFMAs wait for its
@@ -350,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
 //        before its A_p <= #2p+2; group 0 reads after B_p = #2p+2, group 1 after #2p+3.
 //   WAR  ring slot (p+3) % 4 = (p-1) % 4 is overwritten by DMA issued in LOADS_p, i.e. after B_{p-1} >= #2p; all reads
 //        of stage p-1 were complete (lgkmcnt(0)) before the reader's A_{p-1} <= #2p.
+template <bool RM>
 __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int BM = 256, BN = 256, TM = 4, TN = 2;  // four LDS stages
@@ -467,20 +546,38 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
     slot = (slot + 1) & 3;
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
-  f16_finish<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, m0 + BM <= Mend && n0 + BN <= N, lane);
+  if constexpr (RM) {
+    f16_lora_step<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
+    f16_epilogue_lds(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
+  } else {
+    f16_finish<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, m0 + BM <= Mend && n0 + BN <= N, lane);
+  }
 }
 
 static int launch_f16_pp(F16Params& p, hipStream_t stream) {
   p.n_blocks_n = (p.a.N + 255) / 256;
+  {
+    const clipfs_gemm_args& a = p.a;
+    static const int cfg = getenv("CLIPFS_F16_EPILOGUE") ? atoi(getenv("CLIPFS_F16_EPILOGUE")) : 1;  // 0: register epilogue (A/B aid)
+    auto al = [](const void* q, size_t n) { return q == nullptr || ((uintptr_t)q & (n - 1)) == 0; };
+    p.row_major_epilogue = cfg != 0 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && (!a.residual || (a.ldres & 3) == 0) &&
+                           al(a.C, 16) && al(p.C16, 8) && al(a.bias, 16) && al(a.residual, 16) &&
+                           al(a.aux_out, a.aux_f16 ? 8 : 16) && al(a.aux_in, a.aux_f16 ? 8 : 16);
+  }
   const int mb = (p.m_end - p.m_begin + 255) / 256;
   const size_t lds = 4 * (size_t)(2 * 256 * 64);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_pp_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_pp_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_f16_pp_kernel, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  if (p.row_major_epilogue)
+    hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  else
+    hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   return launch_status();
 }
 
@@ -536,6 +633,7 @@ int gemm_f16_dispatch(const clipfs_gemm_args& a, hipStream_t stream) {
   p.C16 = reinterpret_cast<_Float16*>(a.C_f16);
   p.m_begin = 0;
   p.m_end = a.M;
+  p.row_major_epilogue = 0;
   // tuning aid CLIPFS_F16_TILE: 1 / 2 / 3 force the 128x128 / 64x128 / 256x128 4-wave kernel, 4 forces the 256x256
   // ping-pong kernel on every row, 5 disables it
   static const int tile_cfg = getenv("CLIPFS_F16_TILE") ? atoi(getenv("CLIPFS_F16_TILE")) : 0;
