@@ -18,6 +18,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <utility>
+#include <vector>
+
 namespace clipfs {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -222,7 +225,7 @@ __device__ __forceinline__ void f16_finish(const F16Params& p, f32x16 (&acc)[TM]
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -315,26 +318,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[kb][i], bv[kb][j], acc[i][j], 0, 0, 0);
   };
 
-  // Three LDS stages, loads issued two K-steps ahead (a K-step is ~1k cycles of MFMA per SIMD, HBM/L2 latency is
+  // NST = 3 LDS stages, loads issued two K-steps ahead (a K-step is ~1k cycles of MFMA per SIMD, HBM/L2 latency is
   // of that order): at step kt wait until this wave's loads of stage kt have landed (the newer stage may still be
   // in flight), barrier (everyone's stage kt is in LDS and everyone is done reading stage kt-1), refill the stage
-  // kt-1 occupied with step kt+2, compute.
+  // kt-1 occupied with step kt+2, compute.  NST = 2 (24 KiB at 64 x 128: fits beside a 128 KiB ping-pong workgroup,
+  // see gemm_f16_dispatch): one K-step ahead, vmcnt(0) at the barrier.
   constexpr int PER_STAGE = A_INSTR + B_INSTR;  // vmcnt events per wave per stage
   const int nk = K / BK;
   stage_in(0, 0);
-  if (nk > 1) stage_in(1, 1);
-  int cur = 0, nxt = 2;
+  if (NST >= 3 && nk > 1) stage_in(1, 1);
+  int cur = 0, nxt = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk)
+    if (NST >= 3 && kt + 1 < nk)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 2 < nk) stage_in(kt + 2, nxt);
+    if (kt + NST - 1 < nk) stage_in(kt + NST - 1, nxt);
     compute(smem_raw + cur * STAGE);
-    cur = cur == 2 ? 0 : cur + 1;
-    nxt = nxt == 2 ? 0 : nxt + 1;
+    cur = cur == NST - 1 ? 0 : cur + 1;
+    nxt = nxt == NST - 1 ? 0 : nxt + 1;
   }
 
   f16_finish<TM, TN>(p, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), n0, m0 + BM <= Mend && n0 + BN <= N, lane);
@@ -581,19 +585,54 @@ static int launch_f16_pp(F16Params& p, hipStream_t stream) {
   return launch_status();
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST = 3>
 static int launch_f16(F16Params& p, hipStream_t stream) {
   p.n_blocks_n = (p.a.N + BN - 1) / BN;
   const int mb = (p.m_end - p.m_begin + BM - 1) / BM;
-  const size_t lds = 3 * (size_t)(BM * 64 + BN * 64);
+  const size_t lds = NST * (size_t)(BM * 64 + BN * 64);
   static bool attr = false;
   if (!attr && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_kernel<BM, BN, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NST>), dim3(mb * p.n_blocks_n), dim3(256), lds, stream, p);
   return launch_status();
+}
+
+// ---- leftover rows beside the ping-pong kernel ----------------------------------------------------------------
+// The rows the 256 x 256 launch does not take (M mod 256, or a thin last round) are a launch of a few dozen small
+// workgroups whose duration is one tile's K loop (15 - 40 us at K = 1024 ... 4096): behind the big launch on the
+// same stream that is pure latency, ~290 times per cfg-5 step.  A ping-pong workgroup leaves 32 KiB of LDS and 96
+// registers per lane and SIMD free, which is exactly a two-stage 64 x 128 workgroup: the leftover launch goes to a
+// side stream forked off the caller's stream BEFORE the big launch and joined after it, so both grids are resident
+// together and the small one finishes in the shadow of the big one.  One side stream + two events per caller stream,
+// created on first use, per host thread.
+#define F16_HIP(call)                                                          \
+  do {                                                                         \
+    hipError_t _e = (call);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      set_error("gemm_f16: %s failed: %s", #call, hipGetErrorString(_e));      \
+      return CLIPFS_HIPERR_BASE + (int)_e;                                     \
+    }                                                                          \
+  } while (0)
+
+struct SideStream {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
+
+static SideStream* side_stream_for(hipStream_t main) {
+  static thread_local std::vector<std::pair<hipStream_t, SideStream>> table;
+  for (auto& e : table)
+    if (e.first == main) return &e.second;
+  SideStream s;
+  if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
+    return nullptr;
+  table.emplace_back(main, s);
+  return &table.back().second;
 }
 
 // rows [p.m_begin, p.m_end) on the 4-wave kernels: 256 x 128 tiles on the rows that fill whole rounds of 512 workgroup
@@ -653,15 +692,37 @@ int gemm_f16_dispatch(const clipfs_gemm_args& a, hipStream_t stream) {
     const int mb = a.M / 256;  // whole 256-row blocks
     long tiles = (long)mb * nbn;
     int use_mb = mb;
+    static const int fill = getenv("CLIPFS_F16_PP_FILL") ? atoi(getenv("CLIPFS_F16_PP_FILL")) : 30;  // percent
     if (tiles >= cus) {
       const long rem = tiles % cus;
-      if (rem != 0 && rem * 5 < (long)cus * 4) use_mb = (int)((tiles - rem) / nbn);
-    } else if (tiles * 5 < (long)cus * 4) {
+      if (rem != 0 && rem * 100 < (long)cus * fill) use_mb = (int)((tiles - rem) / nbn);
+    } else if (tiles * 100 < (long)cus * fill) {
       use_mb = 0;
     }
     if (use_mb > 0 && (long)use_mb * 256 * 5 >= (long)a.M * 3) {
-      p.m_end = use_mb * 256;
+      const int split = use_mb * 256;
+      static const int side_cfg = getenv("CLIPFS_F16_SIDE") ? atoi(getenv("CLIPFS_F16_SIDE")) : 1;  // 0: same stream (A/B aid)
+      SideStream* side = (side_cfg != 0 && split < a.M) ? side_stream_for(stream) : nullptr;
+      if (side) {
+        // leftover rows first, on the side stream (ordered after everything already queued on `stream`)
+        F16_HIP(hipEventRecord(side->fork, stream));
+        F16_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+        F16Params q = p;
+        q.m_begin = split;
+        q.m_end = a.M;
+        const long small_tiles = (long)((a.M - split + 63) / 64) * ((a.N + 127) / 128);
+        if (small_tiles <= 1024)
+          CLIPFS_CHECK((launch_f16<64, 128, 2>(q, side->stream)));
+        else
+          CLIPFS_CHECK(dispatch_rows_4wave(q, 0, side->stream));
+        F16_HIP(hipEventRecord(side->join, side->stream));
+      }
+      p.m_end = split;
       CLIPFS_CHECK(launch_f16_pp(p, stream));
+      if (side) {
+        F16_HIP(hipStreamWaitEvent(stream, side->join, 0));
+        return CLIPFS_OK;
+      }
       if (p.m_end >= a.M) return CLIPFS_OK;
       p.m_begin = p.m_end;
       p.m_end = a.M;
