@@ -558,6 +558,179 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
   }
 }
 
+// ---- 256 x 256 x 64, four phases per K-tile -------------------------------------------------------------------------
+// The ping-pong kernel above is the guide's "minimum 2-phase" form (one LOADS | MFMA pair of 16 MFMAs per 32-wide
+// K-step).  This one is the finer schedule the guide measures ~1.3x faster (cdna_hip_programming.md, "The 256^2 8-phase
+// template"): the same tile, wave grid (2 x 4, wave tile 128 x 64), 128 KiB of LDS and barrier-staggered wave groups, but
+//   * K-tiles of 64, each computed as FOUR phases of 8 MFMAs (32x32x16) = one 64 x 32 quadrant of the wave tile over
+//     K = 64: quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0), A0/A1 = the wave's rows 0-63 / 64-127, B0/B1 = its columns
+//     0-31 / 32-63, so a phase reads 12 / 4 / 8 / 0 fragments (ds_read_b128) and the other wave of the SIMD, half a
+//     phase behind, always has a quadrant whose operands are in registers;
+//   * the LDS ring is 2 K-tiles x 4 HALF-tiles of 16 KiB, a half-tile = one quadrant operand of ALL waves (A0: rows
+//     wr*128 + [0,64) of both wave rows, B0: columns wc*64 + [0,32) of the four wave columns, ...), stored as
+//     [2 k-planes][128 rows][64 B] with the 16-byte-chunk XOR (row >> 2) & 3 of the other f16 kernels (conflict free);
+//   * ONE half-tile (2 global_load_lds per wave) is staged per phase, in the order the quadrants are read
+//     (A0, B0, B1, A1), five phases ahead of its first read; every phase retires exactly the half-tile the NEXT phase
+//     reads with a counted `s_waitcnt vmcnt(8)`: four half-tiles stay in flight across the barriers, vmcnt never
+//     drains inside the loop.
+// Phase G = 4 t + p (p = 1..4) of K-tile t:  reads {A0,B0 | B1 | A1 | -}(t);  stages sequence element G + 5
+// ({B1,A1}(t+1), {A0,B0}(t+2));  waits until element G + 1 has landed;  barrier;  lgkmcnt(0);  8 MFMAs;  barrier.
+// Hazards (global barrier numbers: group 0 (waves 0-3) passes #2G+1 and #2G+2 in phase G, group 1 one later each):
+//   RAW  element G+1 is retired by every wave before its first barrier of phase G (<= #2G+2) and read in phase G+1
+//        (group 0 after #2G+2, group 1 after #2G+3).  {A0,B0}(t+1) are retired in phases (t,3) and (t,4).
+//   WAR  a slot is restaged >= 2 phases after its last read: A0 / B0 read in (t,1), restaged in (t,3) / (t,4); B1 read
+//        in (t,2), restaged in (t+1,1); A1 read in (t,3), restaged in (t+1,2).  A read of phase G is complete
+//        (lgkmcnt(0)) before the reader's second barrier of that phase (<= #2G+3); the restage of phase G+2 is issued
+//        after #2G+4.
+__global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int BM = 256, BN = 256;
+  constexpr int HPLANE = 128 * 64;   // bytes of one k-plane (32 k) of a half-tile
+  constexpr int HT = 2 * HPLANE;     // 16 KiB
+  constexpr int KT_BYTES = 128;      // bytes of a K-tile along a row
+
+  const clipfs_gemm_args& g = p.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm is also the stagger group
+  const int Mend = p.m_end, N = g.N, K = g.K;
+
+  const int tile = xcd_contiguous_unit();
+  constexpr int GM = 4;
+  const int nbn = p.n_blocks_n;
+  const int grp = tile / (GM * nbn);
+  const int rem = tile - grp * (GM * nbn);
+  const int mb_total = (Mend - p.m_begin + BM - 1) / BM;
+  const int gmm = min(GM, mb_total - grp * GM);
+  const int m0 = p.m_begin + (grp * GM + rem % gmm) * BM;
+  const int n0 = (rem / gmm) * BN;
+
+  // staging: a wave's instruction covers rows 16 wave .. + 15 of a half-tile plane (lane: row l / 4, chunk l % 4); the
+  // swizzle is applied to the SOURCE chunk.  Half-tile types j: 0 = A0, 1 = B0, 2 = B1, 3 = A1.
+  const char *src_a0, *src_b0, *src_b1, *src_a1;
+  {
+    const int r = 16 * wave + (lane >> 2);  // row of the half-tile
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    const int ar = m0 + (r >> 6) * 128 + (r & 63);
+    const int br = n0 + (r >> 5) * 64 + (r & 31);
+    src_a0 = reinterpret_cast<const char*>(p.A16 + (size_t)min(ar, Mend - 1) * g.lda + 8 * c);
+    src_a1 = reinterpret_cast<const char*>(p.A16 + (size_t)min(ar + 64, Mend - 1) * g.lda + 8 * c);
+    src_b0 = reinterpret_cast<const char*>(p.B16 + (size_t)min(br, N - 1) * g.ldb + 8 * c);
+    src_b1 = reinterpret_cast<const char*>(p.B16 + (size_t)min(br + 32, N - 1) * g.ldb + 8 * c);
+  }
+  const int st_off = 16 * wave * 64;
+  // element (K-tile u, type j) -> slot 4 (u & 1) + j
+  auto stage = [&](int u, int j, const char* sp) __attribute__((always_inline)) {
+    char* s = smem_raw + (4 * (u & 1) + j) * HT + st_off;
+    const char* q = sp + (size_t)u * KT_BYTES;
+    glds16(q, s);
+    glds16(q + 64, s + HPLANE);
+  };
+  // fragment addresses inside a half-tile: row R, k-chunk s (0..3 over K = 64): plane s >> 1, 16-byte chunk 2 (s & 1) + fh
+  const int fr = lane & 31, fh = lane >> 5;
+  int a_row[2], a_swz[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int R = wm * 64 + i * 32 + fr;
+    a_row[i] = R * 64;
+    a_swz[i] = (R >> 2) & 3;
+  }
+  const int b_R = wn * 32 + fr;
+  const int b_row = b_R * 64, b_swz = (b_R >> 2) & 3;
+  auto read_a = [&](f16x8 (&f)[2][4], int u, int j) __attribute__((always_inline)) {
+    const char* s = smem_raw + (4 * (u & 1) + j) * HT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        f[i][c] = *reinterpret_cast<const f16x8*>(s + (c >> 1) * HPLANE + a_row[i] + (((2 * (c & 1) + fh) ^ a_swz[i]) << 4));
+  };
+  auto read_b = [&](f16x8 (&f)[4], int u, int j) __attribute__((always_inline)) {
+    const char* s = smem_raw + (4 * (u & 1) + j) * HT;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      f[c] = *reinterpret_cast<const f16x8*>(s + (c >> 1) * HPLANE + b_row + (((2 * (c & 1) + fh) ^ b_swz) << 4));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f16x8 fa0[2][4], fa1[2][4], fb0[4], fb1[4];
+
+#define PH_SYNC_MFMA(VM, FA, FB, I0, J0)                                                          \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");                                       \
+  __builtin_amdgcn_s_barrier();                                                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                  \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) _Pragma("unroll") for (int i = 0; i < 2; ++i)     \
+      acc[I0 + i][J0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i][c], FB[c], acc[I0 + i][J0], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  __builtin_amdgcn_s_barrier();                                                                   \
+  asm volatile("" ::: "memory");
+
+  const int nk = K / 64;  // >= 2 (host)
+  // prologue: K-tile 0 and {A0,B0}(1) in flight; {A0,B0}(0) landed and published
+  stage(0, 0, src_a0);
+  stage(0, 1, src_b0);
+  stage(0, 2, src_b1);
+  stage(0, 3, src_a1);
+  stage(1, 0, src_a0);
+  stage(1, 1, src_b0);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // #0
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 falls one barrier behind
+
+  int t = 0;
+  for (; t + 2 < nk; ++t) {  // steady state: every stage exists, four half-tiles stay in flight
+    read_a(fa0, t, 0);
+    read_b(fb0, t, 1);
+    stage(t + 1, 2, src_b1);
+    PH_SYNC_MFMA(8, fa0, fb0, 0, 0)
+    read_b(fb1, t, 2);
+    stage(t + 1, 3, src_a1);
+    PH_SYNC_MFMA(8, fa0, fb1, 0, 1)
+    read_a(fa1, t, 3);
+    stage(t + 2, 0, src_a0);
+    PH_SYNC_MFMA(8, fa1, fb1, 2, 1)
+    stage(t + 2, 1, src_b0);
+    PH_SYNC_MFMA(8, fa1, fb0, 2, 0)
+  }
+  {  // K-tile nk-2: its phases 3 and 4 have nothing left to stage
+    read_a(fa0, t, 0);
+    read_b(fb0, t, 1);
+    stage(t + 1, 2, src_b1);
+    PH_SYNC_MFMA(8, fa0, fb0, 0, 0)
+    read_b(fb1, t, 2);
+    stage(t + 1, 3, src_a1);
+    PH_SYNC_MFMA(8, fa0, fb1, 0, 1)
+    read_a(fa1, t, 3);
+    PH_SYNC_MFMA(6, fa1, fb1, 2, 1)
+    PH_SYNC_MFMA(4, fa1, fb0, 2, 0)
+    ++t;
+  }
+  {  // K-tile nk-1
+    read_a(fa0, t, 0);
+    read_b(fb0, t, 1);
+    PH_SYNC_MFMA(2, fa0, fb0, 0, 0)
+    read_b(fb1, t, 2);
+    PH_SYNC_MFMA(0, fa0, fb1, 0, 1)
+    read_a(fa1, t, 3);
+    PH_SYNC_MFMA(0, fa1, fb1, 2, 1)
+    PH_SYNC_MFMA(0, fa1, fb0, 2, 0)
+  }
+#undef PH_SYNC_MFMA
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
+  f16_lora_step<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
+  f16_epilogue_lds(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
+}
+
 static int launch_f16_pp(F16Params& p, hipStream_t stream) {
   p.n_blocks_n = (p.a.N + 255) / 256;
   {
@@ -576,9 +749,14 @@ static int launch_f16_pp(F16Params& p, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_pp_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr = true;
   }
-  if (p.row_major_epilogue)
+  static const int ph_cfg = getenv("CLIPFS_F16_PHASED") ? atoi(getenv("CLIPFS_F16_PHASED")) : 1;  // 0: the 2-phase kernel (A/B aid)
+  if (p.row_major_epilogue && ph_cfg != 0 && (p.a.K % 64) == 0 && p.a.K >= 128)
+    hipLaunchKernelGGL(gemm_f16_ph_kernel, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  else if (p.row_major_epilogue)
     hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   else
     hipLaunchKernelGGL(gemm_f16_pp_kernel<false>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);

@@ -400,7 +400,8 @@ def test_gemm_f16_mode(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,lora_r,act", [(300, 256, 64, 0, 0), (2056, 1024, 1024, 16, 0), (1100, 512, 2048, 4, 1),
-                                               (33000, 1024, 256, 0, 2), (700, 384, 128, 0, 0)])
+                                               (33000, 1024, 256, 0, 2), (700, 384, 128, 0, 0),
+                                               (16484, 2048, 128, 16, 1), (8192, 4096, 192, 4, 0), (20480, 1024, 1024, 16, 2)])
 def test_gemm_f16_operands(M, N, K, lora_r, act):
     """f16 x f16 kernel (cfg-5 storage mode): both operands f16 in HBM, fp32 accumulate; f16 products are exact in
     fp32, so against an fp32 matmul of the same rounded operands only the summation order differs (tolerance 2e-5
@@ -442,6 +443,26 @@ def test_gemm_f16_operands(M, N, K, lora_r, act):
     assert (out16.float() - ref).abs().max().item() <= 1e-3 * scale
     if act == 1:
         assert (aux_out - pre).abs().max().item() <= 2e-5 * pre.abs().max().item() + 1e-5
+
+
+@pytest.mark.gpu
+def test_gemm_f16_phased_kernel_is_deterministic_and_matches_two_phase():
+    """The 256 x 256 kernel with four phases per K-tile keeps four half-tiles of LDS-DMA in flight across its barriers:
+    a misplaced wait would show as run-to-run differences or rare wrong tiles.  Ten launches of three shapes (K-tiles
+    2, 3 and 16; 256 - 512 tiles) must be bitwise identical, and equal to the same f16 products summed in torch."""
+    from clipfs import ops
+    for M, N, K in ((16384, 4096, 128), (16384, 4096, 192), (32768, 1024, 1024)):
+        g = torch.Generator().manual_seed(K)
+        a16 = torch.randn(M, K, generator=g).cuda().half()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        w16 = ops.to_f16(w)
+        first = ops.gemm_nt(None, w, b_planes=w16, a16=a16).clone()
+        for _ in range(9):
+            again = ops.gemm_nt(None, w, b_planes=w16, a16=a16)
+            assert torch.equal(first, again), (M, N, K)
+        for r0 in range(0, M, 8192):
+            ref = a16[r0:r0 + 8192].float() @ w16.float().T
+            assert (first[r0:r0 + 8192] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
 
 
 def _attn_ref64(qkv, batch, seq, heads, causal=False):
