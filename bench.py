@@ -31,6 +31,7 @@ until the logits); the instrumented roofline step serialises them so each GEMM's
 from __future__ import annotations
 
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -78,6 +79,9 @@ def parse():
                     help="opt-in: skip the text positions after the batch's last EOT (dead under the causal mask); "
                          "NOT the headline configuration")
     ap.add_argument("--forward-only", action="store_true", help="time the zero-grad image forward only (diagnostic)")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="diagnostic at --gpus 1: an RCCL process group of ONE rank with the step's three collectives "
+                         "issued anyway (their launch / stream cost on one card; no bytes cross xGMI)")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / cfg5 legs after the timed region")
     ap.add_argument("--cfg5-budget-s", type=float, default=150.0,
                     help="skip the cfg-5 leg when the run has already taken this many seconds")
@@ -302,9 +306,22 @@ def main():
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            with stdout_to_stderr():  # RCCL prints a version banner on STDOUT when the communicator is created
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.all_reduce(torch.zeros(1, device=dev))
+                torch.cuda.synchronize()
+    elif args.rccl_one_rank:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
 
     from clipfs import _lib, dist as D, synth
+    if args.rccl_one_rank and world == 1:
+        D.FORCE_COLLECTIVES = True
     lib = _lib.load()
     model, tr, cfg = build_trainer(dev, args)
     top5 = golden_top5(model, tr, dev) if (args.model == "b32" and rank == 0) else None
@@ -349,7 +366,7 @@ def main():
 
     # ---- collectives: three more steps with every collective bracketed by HIP events on its launch stream ----
     coll = None
-    if world > 1 and not args.forward_only:
+    if (world > 1 or args.rccl_one_rank) and not args.forward_only:
         tr.time_collectives = True
         for _ in range(3):
             step()
@@ -497,6 +514,21 @@ def main():
         dist.destroy_process_group()
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File-descriptor level: native libraries (RCCL's start-up banner) write to fd 1 directly, and stdout must carry
+    the JSON line alone."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def collect_roofline(lib, args, precision):
     tms, tfl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
     lib.clipfs_gemm_timing_collect(ctypes.byref(tms), ctypes.byref(tfl), ctypes.byref(n))
@@ -538,11 +570,11 @@ def cfg5_leg(dev, args, lib):
         tr.forward_backward(images, captions, labels, 1, B)
         tr.optimizer_step()
 
-    for _ in range(2):
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    n = 4
+    n = 6
     for _ in range(n):
         step()
     torch.cuda.synchronize()
@@ -556,7 +588,7 @@ def cfg5_leg(dev, args, lib):
     step_tflop = (B * 2 * (162.03 + 0.303) + 403 * 2 * 13.30) / 1e3
     print(f"[bench] cfg5 leg: {dt * 1e3:.1f} ms/step ({time.time() - t0:.0f} s incl. model build)", file=sys.stderr, flush=True)
     return {"workload": "cfg-5 shapes on ONE GPU: ViT-L/14 + rank-16 LoRA (synthetic adapters), fp16 storage mode, 128 images "
-                        "(one rank's share of bs 1024) + 403 captions, train step; 4 steps after 2 warm-ups",
+                        "(one rank's share of bs 1024) + 403 captions, train step; 6 steps after 3 warm-ups",
             "value": round(B / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2),
             "step_tflops": round(step_tflop / dt, 1), "step_frac_of_f16_mfma_peak": round(step_tflop / dt / 2500.0, 4),
             "gemm": roof}

@@ -805,7 +805,13 @@ static SideStream* side_stream_for(hipStream_t main) {
   for (auto& e : table)
     if (e.first == main) return &e.second;
   SideStream s;
-  if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  // highest priority: its own hardware queue (never the one the caller's stream is mapped to), and the few small
+  // workgroups are dispatched as soon as their dependencies are met
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  static const int prio_cfg = getenv("CLIPFS_F16_SIDE_PRIO") ? atoi(getenv("CLIPFS_F16_SIDE_PRIO")) : 0;  // 0 high, 1 low, 2 normal
+  const int prio = prio_cfg == 1 ? least : prio_cfg == 2 ? 0 : greatest;
+  if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
     return nullptr;

@@ -17,7 +17,7 @@ from __future__ import annotations
 import math
 import os
 import pickle
-from typing import Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -651,10 +651,15 @@ class LoRATrainer:
         main.wait_stream(side)
         return loss_sum, correct, logits
 
+    _SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}  # one per device for every trainer of the process (HIP maps
+    # streams onto a handful of hardware queues: a fresh stream per trainer ends up sharing a queue with another one)
+
     def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.model.device)
-        return self._side
+        key = str(self.model.device)
+        if key not in LoRATrainer._SIDE_STREAMS:
+            prio = int(os.environ.get("CLIPFS_SIDE_STREAM_PRIORITY", "-1"))
+            LoRATrainer._SIDE_STREAMS[key] = torch.cuda.Stream(device=self.model.device, priority=prio)
+        return LoRATrainer._SIDE_STREAMS[key]
 
     def optimizer_step(self):
         from clipfs import dist as D
