@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -90,6 +91,41 @@ __device__ __forceinline__ void f16_lora_step(const F16Params& p, f32x16 (&acc)[
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
   }
+}
+
+// the same step for 8 x 4 accumulator tiles of v_mfma_f32_16x16x32_f16 (rank zero-padded to k = 32)
+__device__ __forceinline__ void f16_lora_step16(const F16Params& p, f32x4 (&acc)[8][4], int mw, int nw, int n0, int lane) {
+  const clipfs_gemm_args& g = p.a;
+  if (!g.lora_t) return;
+  const int li = lane & 15, lg = lane >> 4;
+  const int Mend = p.m_end, N = g.N;
+  const int r = g.lora_r;
+  const int seg = n0 / g.lora_seg_width;
+  f16x8 av[8], bv[4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int m = min(mw + t * 16 + li, Mend - 1);
+    const float* tp = g.lora_t + (size_t)m * (g.lora_nseg * r) + seg * r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lg + j;
+      av[t][j] = (_Float16)(tp[min(k, r - 1)] * (k < r ? 1.f : 0.f));
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = min(nw + t * 16 + li, N - 1);
+    const float* lb = g.lora_b + (size_t)n * r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lg + j;
+      bv[t][j] = (_Float16)(lb[min(k, r - 1)] * (k < r ? g.lora_scale : 0.f));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[i], bv[j], acc[i][j], 0, 0, 0);
 }
 
 template <int TM, int TN>
@@ -350,7 +386,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
 // through the LDS ring (128 rows x 256 columns x 4 B = its 128 KiB exactly) and all 512 threads then walk the half tile
 // row-major, 4 columns per thread: bias, saved pre-activation, residual, fp32 C and f16 C16 are all 8 / 16-byte accesses
 // of whole rows (a wave covers one 1 KiB row segment per instruction).
-__device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, f32x16 (&acc)[4][2], float* lds, int m0, int n0, int wm, int wn,
+// T16: the accumulators are 8 x 4 tiles of v_mfma_f32_16x16x32_f16 (lane: column l & 15, rows 4 (l >> 4) + r); a store
+// instruction then covers four row groups 4 rows apart, which all fall on the same 16 banks of a 1 KiB-pitch image -- the
+// 16-float column blocks are XORed with the row group ((row >> 2) & 3) on both sides.
+template <bool T16, class AccT>
+__device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, AccT& acc, float* lds, int m0, int n0, int wm, int wn,
                                                  int tid) {
   const clipfs_gemm_args& g = p.a;
   const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
@@ -360,13 +400,24 @@ __device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, f32x16 (&ac
   for (int half = 0; half < 2; ++half) {
     __syncthreads();  // the ring (or the previous half) is no longer read
     if (wm == half) {
+      if constexpr (T16) {
+        const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            lds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 256 + wn * 64 + j * 32 + fr] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r)
+              lds[(i * 16 + 4 * lg + r) * 256 + ((wn * 64 + j * 16 + li) ^ (16 * lg))] = acc[i][j][r];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              lds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 256 + wn * 64 + j * 32 + fr] = acc[i][j][r];
+      }
     }
     __syncthreads();
 #pragma unroll 4
@@ -375,7 +426,7 @@ __device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, f32x16 (&ac
       const int row = q >> 6, c4 = q & 63;
       const int m = m0 + half * 128 + row, n = n0 + 4 * c4;
       if (m >= Mend || n >= N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * 256 + 4 * c4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * 256 + ((4 * c4) ^ (T16 ? 16 * ((row >> 2) & 3) : 0)));
       if (g.bias) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
         v = g.alpha * v + b4;
@@ -552,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
   if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
   if constexpr (RM) {
     f16_lora_step<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
-    f16_epilogue_lds(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
+    f16_epilogue_lds<false>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
   } else {
     f16_finish<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, m0 + BM <= Mend && n0 + BN <= N, lane);
   }
@@ -582,6 +633,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
 //        in (t,2), restaged in (t+1,1); A1 read in (t,3), restaged in (t+1,2).  A read of phase G is complete
 //        (lgkmcnt(0)) before the reader's second barrier of that phase (<= #2G+3); the restage of phase G+2 is issued
 //        after #2G+4.
+template <bool T16>
 __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int BM = 256, BN = 256;
@@ -626,49 +678,75 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
     glds16(q, s);
     glds16(q + 64, s + HPLANE);
   };
-  // fragment addresses inside a half-tile: row R, k-chunk s (0..3 over K = 64): plane s >> 1, 16-byte chunk 2 (s & 1) + fh
-  const int fr = lane & 31, fh = lane >> 5;
-  int a_row[2], a_swz[2];
+  // fragment addresses inside a half-tile: row R, plane pl (32 k each), 16-byte chunk c of the row's 64 bytes.
+  //   32x32x16: lane = row l & 31, K-step s (two per plane) -> chunk 2 s + (l >> 5);   tiles: A 2 per quadrant, B 1
+  //   16x16x32: lane = row l & 15, one K-step per plane   -> chunk l >> 4;            tiles: A 4 per quadrant, B 2
+  constexpr int NA = T16 ? 4 : 2, NB = T16 ? 2 : 1;  // tiles of a quadrant operand
+  constexpr int TR = T16 ? 16 : 32;                  // tile rows
+  const int fr = lane & (TR - 1), fh = lane / TR;    // fh: 0..1 (32-row tiles) / 0..3 (16-row tiles)
+  int a_row[NA], a_swz[NA], b_row[NB], b_swz[NB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int R = wm * 64 + i * 32 + fr;
+  for (int i = 0; i < NA; ++i) {
+    const int R = wm * 64 + i * TR + fr;
     a_row[i] = R * 64;
     a_swz[i] = (R >> 2) & 3;
   }
-  const int b_R = wn * 32 + fr;
-  const int b_row = b_R * 64, b_swz = (b_R >> 2) & 3;
-  auto read_a = [&](f16x8 (&f)[2][4], int u, int j) __attribute__((always_inline)) {
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int R = wn * 32 + i * TR + fr;
+    b_row[i] = R * 64;
+    b_swz[i] = (R >> 2) & 3;
+  }
+  // fragment c of a tile: plane c >> 1 (32x32x16: K-step c & 1 of it) / plane c (16x16x32)
+  constexpr int NC = T16 ? 2 : 4;
+  auto read_a = [&](f16x8 (&f)[NA][NC], int u, int j) __attribute__((always_inline)) {
     const char* s = smem_raw + (4 * (u & 1) + j) * HT;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        f[i][c] = *reinterpret_cast<const f16x8*>(s + (c >> 1) * HPLANE + a_row[i] + (((2 * (c & 1) + fh) ^ a_swz[i]) << 4));
+      for (int c = 0; c < NC; ++c) {
+        const int pl = T16 ? c : (c >> 1), ch = T16 ? fh : 2 * (c & 1) + fh;
+        f[i][c] = *reinterpret_cast<const f16x8*>(s + pl * HPLANE + a_row[i] + ((ch ^ a_swz[i]) << 4));
+      }
   };
-  auto read_b = [&](f16x8 (&f)[4], int u, int j) __attribute__((always_inline)) {
+  auto read_b = [&](f16x8 (&f)[NB][NC], int u, int j) __attribute__((always_inline)) {
     const char* s = smem_raw + (4 * (u & 1) + j) * HT;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      f[c] = *reinterpret_cast<const f16x8*>(s + (c >> 1) * HPLANE + b_row + (((2 * (c & 1) + fh) ^ b_swz) << 4));
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int pl = T16 ? c : (c >> 1), ch = T16 ? fh : 2 * (c & 1) + fh;
+        f[i][c] = *reinterpret_cast<const f16x8*>(s + pl * HPLANE + b_row[i] + ((ch ^ b_swz[i]) << 4));
+      }
   };
 
-  f32x16 acc[4][2];
+  typedef typename std::conditional<T16, f32x4, f32x16>::type acc_t;
+  acc_t acc[2 * NA][2 * NB];  // [row tile][column tile] of the 128 x 64 wave tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2 * NA; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2 * NB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  f16x8 fa0[2][4], fa1[2][4], fb0[4], fb1[4];
+      for (int r = 0; r < (T16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+  f16x8 fa0[NA][NC], fa1[NA][NC], fb0[NB][NC], fb1[NB][NC];
 
+  // one quadrant: rows I0 .., columns J0 .. (in tiles); 8 (32x32x16) or 16 (16x16x32) MFMAs, K-step outermost so that
+  // consecutive MFMAs never share an accumulator
 #define PH_SYNC_MFMA(VM, FA, FB, I0, J0)                                                          \
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");                                       \
   __builtin_amdgcn_s_barrier();                                                                   \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
   __builtin_amdgcn_sched_barrier(0);                                                              \
   __builtin_amdgcn_s_setprio(1);                                                                  \
-  _Pragma("unroll") for (int c = 0; c < 4; ++c) _Pragma("unroll") for (int i = 0; i < 2; ++i)     \
-      acc[I0 + i][J0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i][c], FB[c], acc[I0 + i][J0], 0, 0, 0); \
+  _Pragma("unroll") for (int c = 0; c < NC; ++c) _Pragma("unroll") for (int i = 0; i < NA; ++i)   \
+      _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                            \
+    if constexpr (T16)                                                                            \
+      acc[I0 * NA + i][J0 * NB + j] =                                                             \
+          __builtin_amdgcn_mfma_f32_16x16x32_f16(FA[i][c], FB[j][c], acc[I0 * NA + i][J0 * NB + j], 0, 0, 0); \
+    else                                                                                          \
+      acc[I0 * NA + i][J0 * NB + j] =                                                             \
+          __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i][c], FB[j][c], acc[I0 * NA + i][J0 * NB + j], 0, 0, 0); \
+  }                                                                                               \
   __builtin_amdgcn_s_setprio(0);                                                                  \
   __builtin_amdgcn_sched_barrier(0);                                                              \
   __builtin_amdgcn_s_barrier();                                                                   \
@@ -698,9 +776,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
     PH_SYNC_MFMA(8, fa0, fb1, 0, 1)
     read_a(fa1, t, 3);
     stage(t + 2, 0, src_a0);
-    PH_SYNC_MFMA(8, fa1, fb1, 2, 1)
+    PH_SYNC_MFMA(8, fa1, fb1, 1, 1)
     stage(t + 2, 1, src_b0);
-    PH_SYNC_MFMA(8, fa1, fb0, 2, 0)
+    PH_SYNC_MFMA(8, fa1, fb0, 1, 0)
   }
   {  // K-tile nk-2: its phases 3 and 4 have nothing left to stage
     read_a(fa0, t, 0);
@@ -711,8 +789,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
     stage(t + 1, 3, src_a1);
     PH_SYNC_MFMA(8, fa0, fb1, 0, 1)
     read_a(fa1, t, 3);
-    PH_SYNC_MFMA(6, fa1, fb1, 2, 1)
-    PH_SYNC_MFMA(4, fa1, fb0, 2, 0)
+    PH_SYNC_MFMA(6, fa1, fb1, 1, 1)
+    PH_SYNC_MFMA(4, fa1, fb0, 1, 0)
     ++t;
   }
   {  // K-tile nk-1
@@ -722,13 +800,16 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
     read_b(fb1, t, 2);
     PH_SYNC_MFMA(0, fa0, fb1, 0, 1)
     read_a(fa1, t, 3);
-    PH_SYNC_MFMA(0, fa1, fb1, 2, 1)
-    PH_SYNC_MFMA(0, fa1, fb0, 2, 0)
+    PH_SYNC_MFMA(0, fa1, fb1, 1, 1)
+    PH_SYNC_MFMA(0, fa1, fb0, 1, 0)
   }
 #undef PH_SYNC_MFMA
   if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
-  f16_lora_step<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
-  f16_epilogue_lds(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
+  if constexpr (T16)
+    f16_lora_step16(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
+  else
+    f16_lora_step<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
+  f16_epilogue_lds<T16>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
 }
 
 static int launch_f16_pp(F16Params& p, hipStream_t stream) {
@@ -749,13 +830,23 @@ static int launch_f16_pp(F16Params& p, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_pp_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  static const int ph_cfg = getenv("CLIPFS_F16_PHASED") ? atoi(getenv("CLIPFS_F16_PHASED")) : 1;  // 0: the 2-phase kernel (A/B aid)
-  if (p.row_major_epilogue && ph_cfg != 0 && (p.a.K % 64) == 0 && p.a.K >= 128)
-    hipLaunchKernelGGL(gemm_f16_ph_kernel, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  static const int ph_cfg = getenv("CLIPFS_F16_PHASED") ? atoi(getenv("CLIPFS_F16_PHASED")) : 1;  // 0: the 2-phase kernel, 2 / 3: phased on 32x32x16 / 16x16x32 MFMAs always (A/B aids)
+  // MFMA shape of the phased kernel.  The board sits at its power cap under f16 MFMA load and holds a higher clock on
+  // 16x16x32 than on 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7): 1.56 vs 1.69 us per K-tile and round
+  // (M = 32768, N = 4096, scripts/ksweep_f16.py), but its tile costs ~2 us more outside the K loop (the 8 x 4-tile
+  // accumulator layout: 256 registers, spills around the epilogue) -- so 16x16x32 from K = 1536 up.
+  const bool phased = p.row_major_epilogue && ph_cfg != 0 && (p.a.K % 64) == 0 && p.a.K >= 128;
+  const bool shape16 = ph_cfg == 3 || (ph_cfg == 1 && p.a.K >= 1536);
+  if (phased && shape16)
+    hipLaunchKernelGGL(gemm_f16_ph_kernel<true>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  else if (phased)
+    hipLaunchKernelGGL(gemm_f16_ph_kernel<false>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   else if (p.row_major_epilogue)
     hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   else

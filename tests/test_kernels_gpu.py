@@ -401,7 +401,8 @@ def test_gemm_f16_mode(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,lora_r,act", [(300, 256, 64, 0, 0), (2056, 1024, 1024, 16, 0), (1100, 512, 2048, 4, 1),
                                                (33000, 1024, 256, 0, 2), (700, 384, 128, 0, 0),
-                                               (16484, 2048, 128, 16, 1), (8192, 4096, 192, 4, 0), (20480, 1024, 1024, 16, 2)])
+                                               (16484, 2048, 128, 16, 1), (8192, 4096, 192, 4, 0), (20480, 1024, 1024, 16, 2),
+                                               (16640, 1024, 2048, 16, 1), (16384, 2048, 1536, 4, 2)])
 def test_gemm_f16_operands(M, N, K, lora_r, act):
     """f16 x f16 kernel (cfg-5 storage mode): both operands f16 in HBM, fp32 accumulate; f16 products are exact in
     fp32, so against an fp32 matmul of the same rounded operands only the summation order differs (tolerance 2e-5
@@ -451,7 +452,7 @@ def test_gemm_f16_phased_kernel_is_deterministic_and_matches_two_phase():
     a misplaced wait would show as run-to-run differences or rare wrong tiles.  Ten launches of three shapes (K-tiles
     2, 3 and 16; 256 - 512 tiles) must be bitwise identical, and equal to the same f16 products summed in torch."""
     from clipfs import ops
-    for M, N, K in ((16384, 4096, 128), (16384, 4096, 192), (32768, 1024, 1024)):
+    for M, N, K in ((16384, 4096, 128), (16384, 4096, 192), (32768, 1024, 1024), (16384, 1024, 2048)):  # last: 16x16x32
         g = torch.Generator().manual_seed(K)
         a16 = torch.randn(M, K, generator=g).cuda().half()
         w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
