@@ -96,6 +96,10 @@ typedef struct clipfs_gemm_args {
                               (the kernel leaves them zero); with `workspace` enables the stream-K schedule */
   size_t counters_ints;
 } clipfs_gemm_args;
+/* Ordering: everything the call does is ordered on `stream` (work queued on it before the call happens-before, work
+ * queued after it happens-after).  The f16 x f16 path may run part of the rows on an internal high-priority side
+ * stream, forked from and joined back into `stream` with events inside the call (one side stream per caller stream
+ * and host thread, created on first use). */
 int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
 /* Products with few output tiles (small per-rank batches) are cut along K into `clipfs_gemm_splits` slices
  * whose raw partial sums go to `workspace` and are combined, in slice order, by a second kernel that applies
