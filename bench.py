@@ -540,7 +540,7 @@ def collect_roofline(lib, args, precision):
     kname, peak = {
         "fp32": ("gemm_nt_kernel<64,128,3> (v_mfma_f32_32x32x2_f32, global_load_lds staging)", FP32_MFMA_PEAK_TFLOPS),
         "bf16x3": ("gemm_bf16x3_kernel<.,.,2> (3 x v_mfma_f32_32x32x16_bf16 per operand pair)", 2500.0 / 3),
-        "fp16": ("gemm_f16_ph_kernel 256x256x64, four quadrant phases per K-tile (v_mfma_f32_32x32x16_f16, 16x16x32 from K = 1536; "
+        "fp16": ("gemm_f16_ph_kernel 256x256x64, four quadrant phases per K-tile (v_mfma_f32_16x16x32_f16; "
                  "both operands f16 via global_load_lds) + gemm_f16_kernel<64,128,2> on the leftover rows beside it; peak = the "
                  "2.5 PFLOP/s spec, the board holds 1.75 GHz of 2.4 under this load (1.4 kW cap)", 2500.0),
     }[precision]

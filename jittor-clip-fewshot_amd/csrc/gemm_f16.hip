@@ -101,17 +101,7 @@ __device__ __forceinline__ void f16_lora_step16(const F16Params& p, f32x4 (&acc)
   const int Mend = p.m_end, N = g.N;
   const int r = g.lora_r;
   const int seg = n0 / g.lora_seg_width;
-  f16x8 av[8], bv[4];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int m = min(mw + t * 16 + li, Mend - 1);
-    const float* tp = g.lora_t + (size_t)m * (g.lora_nseg * r) + seg * r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 8 * lg + j;
-      av[t][j] = (_Float16)(tp[min(k, r - 1)] * (k < r ? 1.f : 0.f));
-    }
-  }
+  f16x8 bv[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int n = min(nw + t * 16 + li, N - 1);
@@ -120,6 +110,17 @@ __device__ __forceinline__ void f16_lora_step16(const F16Params& p, f32x4 (&acc)
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * lg + j;
       bv[t][j] = (_Float16)(lb[min(k, r - 1)] * (k < r ? g.lora_scale : 0.f));
+    }
+  }
+  f16x8 av[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int m = min(mw + t * 16 + li, Mend - 1);
+    const float* tp = g.lora_t + (size_t)m * (g.lora_nseg * r) + seg * r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * lg + j;
+      av[t][j] = (_Float16)(tp[min(k, r - 1)] * (k < r ? 1.f : 0.f));
     }
   }
 #pragma unroll
@@ -760,6 +761,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
   stage(0, 3, src_a1);
   stage(1, 0, src_a0);
   stage(1, 1, src_b0);
+  // 16x16x32: the LoRA term goes into the accumulators FIRST, while no fragment registers are live (its 48 operand
+  // registers beside 128 accumulators and 64 fragments spilled around the last K-tile when it came last).  Its loads are
+  // younger than the LDS-DMA above, so waiting for them retires the whole prologue: the counted wait below then falls through.
+  if constexpr (T16) f16_lora_step16(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // #0
   asm volatile("" ::: "memory");
@@ -804,11 +809,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
     PH_SYNC_MFMA(0, fa1, fb0, 1, 0)
   }
 #undef PH_SYNC_MFMA
+  __builtin_amdgcn_sched_barrier(0);  // nothing of the epilogue (LoRA operand loads) is hoisted into the last phases
   if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
-  if constexpr (T16)
-    f16_lora_step16(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
-  else
-    f16_lora_step<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
+  if constexpr (!T16) f16_lora_step<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
   f16_epilogue_lds<T16>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
 }
 
@@ -836,13 +839,13 @@ static int launch_f16_pp(F16Params& p, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  static const int ph_cfg = getenv("CLIPFS_F16_PHASED") ? atoi(getenv("CLIPFS_F16_PHASED")) : 1;  // 0: the 2-phase kernel, 2 / 3: phased on 32x32x16 / 16x16x32 MFMAs always (A/B aids)
+  static const int ph_cfg = getenv("CLIPFS_F16_PHASED") ? atoi(getenv("CLIPFS_F16_PHASED")) : 1;  // 0: the 2-phase kernel, 2: phased on 32x32x16 MFMAs (A/B aids)
   // MFMA shape of the phased kernel.  The board sits at its power cap under f16 MFMA load and holds a higher clock on
-  // 16x16x32 than on 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7): 1.56 vs 1.69 us per K-tile and round
-  // (M = 32768, N = 4096, scripts/ksweep_f16.py), but its tile costs ~2 us more outside the K loop (the 8 x 4-tile
-  // accumulator layout: 256 registers, spills around the epilogue) -- so 16x16x32 from K = 1536 up.
+  // 16x16x32 than on 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7): 1.58 vs 1.76 us per K-tile and round at
+  // M = 32768, N = 4096 (scripts/ksweep_f16.py: K = 128 ... 4096 150.6 ... 915.3 us vs 154.1 ... 1000.8), so 16x16x32
+  // is the default; 32x32x16 stays as CLIPFS_F16_PHASED=2.
   const bool phased = p.row_major_epilogue && ph_cfg != 0 && (p.a.K % 64) == 0 && p.a.K >= 128;
-  const bool shape16 = ph_cfg == 3 || (ph_cfg == 1 && p.a.K >= 1536);
+  const bool shape16 = ph_cfg != 2;
   if (phased && shape16)
     hipLaunchKernelGGL(gemm_f16_ph_kernel<true>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   else if (phased)
