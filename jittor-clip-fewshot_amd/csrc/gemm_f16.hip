@@ -614,8 +614,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
 // The ping-pong kernel above is the guide's "minimum 2-phase" form (one LOADS | MFMA pair of 16 MFMAs per 32-wide
 // K-step).  This one is the finer schedule the guide measures ~1.3x faster (cdna_hip_programming.md, "The 256^2 8-phase
 // template"): the same tile, wave grid (2 x 4, wave tile 128 x 64), 128 KiB of LDS and barrier-staggered wave groups, but
-//   * K-tiles of 64, each computed as FOUR phases of 8 MFMAs (32x32x16) = one 64 x 32 quadrant of the wave tile over
-//     K = 64: quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0), A0/A1 = the wave's rows 0-63 / 64-127, B0/B1 = its columns
+//   * K-tiles of 64, each computed as FOUR phases of 16 MFMAs (16x16x32; T16 = false: 8 of 32x32x16, the A/B aid) = one
+//     64 x 32 quadrant of the wave tile over K = 64: quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0), A0/A1 = the wave's rows 0-63 / 64-127, B0/B1 = its columns
 //     0-31 / 32-63, so a phase reads 12 / 4 / 8 / 0 fragments (ds_read_b128) and the other wave of the SIMD, half a
 //     phase behind, always has a quadrant whose operands are in registers;
 //   * the LDS ring is 2 K-tiles x 4 HALF-tiles of 16 KiB, a half-tile = one quadrant operand of ALL waves (A0: rows
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
 //     reads with a counted `s_waitcnt vmcnt(8)`: four half-tiles stay in flight across the barriers, vmcnt never
 //     drains inside the loop.
 // Phase G = 4 t + p (p = 1..4) of K-tile t:  reads {A0,B0 | B1 | A1 | -}(t);  stages sequence element G + 5
-// ({B1,A1}(t+1), {A0,B0}(t+2));  waits until element G + 1 has landed;  barrier;  lgkmcnt(0);  8 MFMAs;  barrier.
+// ({B1,A1}(t+1), {A0,B0}(t+2));  waits until element G + 1 has landed;  barrier;  lgkmcnt(0);  the MFMAs;  barrier.
 // Hazards (global barrier numbers: group 0 (waves 0-3) passes #2G+1 and #2G+2 in phase G, group 1 one later each):
 //   RAW  element G+1 is retired by every wave before its first barrier of phase G (<= #2G+2) and read in phase G+1
 //        (group 0 after #2G+2, group 1 after #2G+3).  {A0,B0}(t+1) are retired in phases (t,3) and (t,4).
