@@ -476,6 +476,40 @@ def test_fp16_precision_mode_l14(dev, monkeypatch):
     assert (g16 - g32).abs().max().item() < 3e-2 * g32.abs().max().item()
 
 
+def test_fp16_step_at_cfg5_row_counts_is_bitwise_reproducible(dev, monkeypatch):
+    """ViT-L/14 shapes at cfg-5's ROW counts (128 images x 257 tokens, 403 captions x 77; depth 2 + 2): the tower GEMMs run
+    on the 256 x 256 phased kernel (LDS-DMA in flight across barriers, wave groups one barrier apart) with their leftover
+    rows on the side stream, the two towers on two streams.  A misplaced wait or a missing join shows as run-to-run
+    differences: six steps with the same dropout seed must give bitwise identical logits and gradients."""
+    import dataclasses
+    import lora_train_vlp as L
+    from clipfs import synth
+    cfg = dataclasses.replace(synth.VIT_L14, vision_layers=2, transformer_layers=2, vocab_size=2048)
+    sd, model = _build(cfg, dev, seed=17)
+    args = _args("ViT-L/14", r=16, p=0.25)
+    lw = synth.synth_lora(cfg, 16, seed=5)
+    _apply(model, cfg, args, lw, monkeypatch)
+    B, Cn = 128, 403
+    img = synth.synth_images(B, 224, seed=3).to(dev)
+    cap = synth.synth_captions(Cn, 77, cfg.vocab_size, seed=4).to(dev)
+    tgt = synth.synth_labels(B, Cn, seed=2).to(dev)
+    model.train()
+    model.engine.precision = "fp16"
+    tr = L.LoRATrainer(model)
+    ref = None
+    for i in range(6):
+        model.engine.step = 11  # the same Philox seed every time
+        tr.flat.zero_grad()
+        _, _, logits = tr.forward_backward(img, cap, tgt)
+        torch.cuda.synchronize()
+        got = (logits.clone(), tr.flat.grads.clone())
+        assert torch.isfinite(got[1]).all() and got[1].abs().max() > 0
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f"run {i} differs"
+
+
 def test_three_step_training_trajectory(dev, monkeypatch):
     """Three consecutive LoRATrainer.step calls (LoRA dropout 0.25 with a fresh Philox seed per step, prompt ctx, AdamW
     moments carried across steps) against the oracle run as a loop: per-step loss and the trainables after step 3."""
