@@ -54,6 +54,9 @@ TXT_FWD, TXT_BWD = 5.9595 + 0.0227, 5.959 + 0.045
 # count so that step_tflops prices only work an exact implementation has to do (GFLOP per image / caption):
 IMG_BWD_ZERO = 9 * 768 * 768 * 2 * 49 / 1e9
 TXT_BWD_ZERO = 9 * 512 * 512 * 2 * 76 / 1e9
+# The forward has the same structure: after the last attention nothing but the class / EOT row is ever read, so the last
+# block's output projection, LayerNorm 2 and MLP (the same 9 d^2 MACs per token) run on that row (clipfs_tower_fwd_rows):
+IMG_FWD_ZERO, TXT_FWD_ZERO = IMG_BWD_ZERO, TXT_BWD_ZERO
 
 
 def parse():
@@ -398,7 +401,7 @@ def main():
     if world == 1 and not args.no_variants and not args.forward_only and args.model == "b32" and \
             args.precision == "fp32" and not args.trim_text:
         variants = {}
-        # the same step with every block's backward dense (the one-row-per-sequence gradient scattered into zeros first)
+        # the same step with every block dense in both directions (the one-row-per-sequence gradient scattered into zeros)
         model.engine.sparse_backward = False
         step()
         torch.cuda.synchronize()
@@ -408,10 +411,11 @@ def main():
         torch.cuda.synchronize()
         vdt = (time.perf_counter() - t1) / 3
         model.engine.sparse_backward = True
-        variants["dense_last_block_backward"] = {
+        variants["dense_last_block"] = {
             "value": round(gb / vdt, 2), "unit": "images/s", "ms_per_step": round(vdt * 1e3, 3),
-            "note": "identical gradients; the last block's MLP / out-proj input-gradients computed for all 12 800 + 31 031 rows "
-                    "although only the 256 class-token + 403 EOT rows are non-zero (what round 1 measured)"}
+            "note": "identical features and gradients; the last block's out-proj / LayerNorm 2 / MLP and their input-gradients "
+                    "computed for all 12 800 + 31 031 rows although only the 256 class-token + 403 EOT rows are read / non-zero "
+                    "(what round 1 measured; algorithmic 9.303 TFLOP per step)"}
         for name, trim, prec, note in (
                 ("trim_text", True, "fp32", "exact fp32; text tower evaluated only up to the last EOT of the batch (positions "
                                             "after a caption's EOT cannot reach its feature under the causal mask)"),
@@ -443,10 +447,11 @@ def main():
                 model.engine.vit_forward(images, False)
             torch.cuda.synchronize()
         fdt = (time.perf_counter() - t1) / 10
-        ftf = gb * IMG_FWD / 1e3 / fdt
+        ftf = gb * (IMG_FWD - (IMG_FWD_ZERO if model.engine.sparse_backward else 0)) / 1e3 / fdt
         fwd_only = {"value": round(gb / fdt, 1), "unit": "images/s", "ms": round(fdt * 1e3, 3), "batch": gb,
                     "tflops": round(ftf, 2), "frac_of_fp32_mfma_peak": round(ftf / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "workload": "ViT-B/32 image tower forward (eval, LoRA applied, no dropout), 10 passes after 3 warm-ups",
+                    "workload": "ViT-B/32 image tower forward (eval, LoRA applied, no dropout), 10 passes after 3 warm-ups; the last "
+                                "block after its attention on the class-token rows only (8.319 algorithmic GFLOP per image)",
                     "north_star_target": ">= 0.40 of the MFMA roofline"}
 
     # ---- cfg-5 leg: ViT-L/14, rank-16 LoRA, fp16 storage mode, 128 images (one rank's share of bs 1024) + 403 captions ----
@@ -465,11 +470,12 @@ def main():
         if args.model == "l14":  # 162.03 (+0.303 LoRA) per image, 13.30 per caption; dgrad ~= forward
             step_tflop = (gb * 2 * (162.03 + 0.303) + args.classes * 2 * 13.30) / 1e3
         elif args.forward_only:
-            step_tflop = gb * IMG_FWD / 1e3
+            dense_bwd = os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
+            step_tflop = gb * (IMG_FWD - (0 if dense_bwd else IMG_FWD_ZERO)) / 1e3
         else:
             dense_bwd = os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
-            step_tflop = (gb * (IMG_FWD + IMG_BWD - (0 if dense_bwd else IMG_BWD_ZERO)) +
-                          args.classes * (TXT_FWD + TXT_BWD - (0 if dense_bwd else TXT_BWD_ZERO))) / 1e3
+            step_tflop = (gb * (IMG_FWD + IMG_BWD - (0 if dense_bwd else IMG_FWD_ZERO + IMG_BWD_ZERO)) +
+                          args.classes * (TXT_FWD + TXT_BWD - (0 if dense_bwd else TXT_FWD_ZERO + TXT_BWD_ZERO))) / 1e3
         backend = D.backend_name()
         out = {
             "metric": "images/sec ViT-B/32 fwd+LoRA-bwd bs=256" if args.model == "b32" else
@@ -482,8 +488,9 @@ def main():
                                    "fwd+bwd on 403 captions + image tower fwd+bwd + 100*cos CE + AdamW"
                        if not args.forward_only else "ViT-B/32 image tower forward only (diagnostic)",
                        "global_batch": gb, "images_per_rank": n_img_local, "captions": args.classes,
-                       "last_block_backward": "dense (CLIPFS_DENSE_BWD=1)" if os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
-                       else "one row per sequence (the rows with non-zero gradient; exact)",
+                       "last_block": "dense (CLIPFS_DENSE_BWD=1)" if os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
+                       else "after its attention, forward and backward on one row per sequence (the class / EOT row: the only "
+                            "row read, the only row with gradient; exact -- `variants.dense_last_block` is the all-rows step)",
                        "lora_dropout": args.dropout, "tower_streams": 1 if args.serial_towers else 2, "text_positions": "trimmed-to-last-EOT" if args.trim_text else 77, "parallelism": f"dp{world}" + ("" if args.no_shard_text or world == 1 else "+class-sharded-text")},
             "algorithmic_tflop_per_step": round(step_tflop, 3),
             "step_tflops": round(step_tflop / (ms * 1e-3), 2),

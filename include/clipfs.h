@@ -229,6 +229,11 @@ int clipfs_scatter_rows(const float* dy, const int32_t* idx, float* dx, int n, i
 int clipfs_gather_seq_rows(const float* src, size_t ld, const int32_t* idx, float* out, int n, int seq, int width,
                            void* stream);
 int clipfs_add_seq_rows(const float* src, const int32_t* idx, float* dx, int n, int seq, int width, void* stream);
+/*   put:     dst[(c*seq + idx[c]) * ld + 0..width) = src[c, :]  (other rows untouched; clipfs_tower_fwd_rows)
+ *   eot_index: idx[c] = argmax_l ids[c, l], first maximum (the EOT position, jclip/model.py:213-214) */
+int clipfs_put_seq_rows(const float* src, const int32_t* idx, float* dst, size_t ld, int n, int seq, int width,
+                        void* stream);
+int clipfs_eot_index(const int64_t* ids, int32_t* idx, int n, int seq, void* stream);
 
 /* --------------------------------------------------------- BPE tokenizer --
  * Native merge loop of the CLIP byte-pair encoder (jclip/simple_tokenizer.py:88-129; host code, no GPU work).
@@ -362,6 +367,17 @@ size_t clipfs_tower_counter_ints(const clipfs_tower* t, int batch);
 /* x [batch*seq, width] in/out (residual stream, updated in place).  saved == NULL: inference
  * (nothing kept); else activations for clipfs_tower_bwd are written to `saved`. */
 int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, float* scratch, void* stream);
+/* The same forward when the caller reads ONE row per sequence of the result (rows[c] = its token index: the class token,
+ * jclip/model.py:121-124, or the EOT token, :213-214).  In the LAST block everything after the attention is row-wise,
+ * so the output projection, LayerNorm 2 and the MLP run on `batch` rows instead of batch*seq: 9 d^2 MACs per skipped
+ * token, 5.9 % of the image tower's forward and 6.0 % of the text tower's at cfg-2.  On return x holds the block output
+ * at rows c*seq + rows[c] ONLY (the other rows keep the last block's input); `saved` is complete for
+ * clipfs_tower_bwd_sparse with the same rows and NOT for clipfs_tower_bwd.  Falls back to clipfs_tower_fwd in the
+ * cases clipfs_tower_bwd_sparse falls back (clipfs_tower_rows_mode() == 0: fp16 storage mode, an o-projection adapter
+ * in the last block, seq < 8, CLIPFS_DENSE_BWD=1), so the two always agree. */
+int clipfs_tower_fwd_rows(const clipfs_tower* t, float* x, const int32_t* rows, int batch, float* saved, float* scratch,
+                          void* stream);
+int clipfs_tower_rows_mode(const clipfs_tower* t);
 /* dx [batch*seq, width] in/out: gradient wrt the tower output on entry, wrt its input on exit.
  * stop_at_input != 0: the gradient wrt the tower input is not needed (image tower without VPT:
  * block 0's LN1 backward and q/k/v dgrad are skipped). */

@@ -99,6 +99,8 @@ SIGNATURES = {
     "clipfs_scatter_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "clipfs_gather_seq_rows": (_i, [_p, _sz, _p, _p, _i, _i, _i, _p]),
     "clipfs_add_seq_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "clipfs_put_seq_rows": (_i, [_p, _p, _p, _sz, _i, _i, _i, _p]),
+    "clipfs_eot_index": (_i, [_p, _p, _i, _i, _p]),
     "clipfs_l2norm_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
     "clipfs_l2norm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "clipfs_class_mean_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -126,6 +128,8 @@ SIGNATURES = {
     "clipfs_tower_scratch_floats": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_counter_ints": (_sz, [C.POINTER(Tower), _i]),
     "clipfs_tower_fwd": (_i, [C.POINTER(Tower), _p, _i, _p, _p, _p]),
+    "clipfs_tower_fwd_rows": (_i, [C.POINTER(Tower), _p, _p, _i, _p, _p, _p]),
+    "clipfs_tower_rows_mode": (_i, [C.POINTER(Tower)]),
     "clipfs_tower_bwd": (_i, [C.POINTER(Tower), _p, _i, _p, _p, _i, _p]),
     "clipfs_tower_bwd_sparse": (_i, [C.POINTER(Tower), _p, _p, _p, _i, _p, _p, _i, _p]),
 }

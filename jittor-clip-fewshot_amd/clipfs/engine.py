@@ -155,7 +155,7 @@ class _TowerRT:
         t.gemm_counters, t.gemm_counters_ints = buf.data_ptr(), buf.numel()
 
     def forward(self, x: torch.Tensor, batch: int, train: bool, seed: int, seq: Optional[int] = None,
-                own_saved: bool = False, row0: int = 0):
+                own_saved: bool = False, row0: int = 0, rows: Optional[torch.Tensor] = None):
         """``train`` = keep the activations the backward needs.  ``own_saved``: give this call its OWN saved-activation
         tensor (the autograd route: several grad-enabled forwards of one tower may precede one backward, e.g. the 13
         caption chunks of encode_text_in_batches, lora_train_vlp.py:905-912); otherwise the per-tower cached buffer
@@ -169,8 +169,15 @@ class _TowerRT:
             n = lib.clipfs_tower_saved_floats(C.byref(t), batch)
             saved = torch.empty(max(n, 4), device=x.device, dtype=torch.float32) if own_saved else \
                 self.buffer("saved", n, x.device)
-        check(lib.clipfs_tower_fwd(C.byref(t), x.data_ptr(), batch, _ptr(saved), scratch.data_ptr(),
-                                   torch.cuda.current_stream().cuda_stream), "tower_fwd")
+        if rows is not None:
+            # the caller reads one row per sequence (``rows`` [batch] int32): the last block's output projection and MLP
+            # run on those rows only; the matching backward is ``backward_sparse`` with the same rows
+            assert rows.dtype == torch.int32 and rows.is_cuda and rows.numel() >= batch
+            check(lib.clipfs_tower_fwd_rows(C.byref(t), x.data_ptr(), rows.data_ptr(), batch, _ptr(saved), scratch.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "tower_fwd_rows")
+        else:
+            check(lib.clipfs_tower_fwd(C.byref(t), x.data_ptr(), batch, _ptr(saved), scratch.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "tower_fwd")
         return saved
 
     def backward(self, dx: torch.Tensor, batch: int, saved: torch.Tensor, seed: int, stop_at_input: bool,
@@ -214,9 +221,11 @@ class Engine:
         # the reference's rows EOT+1..76 (jclip/model.py:202-215 encodes all 77) are dead work.
         self.trim_text = False
         self._trim_cache = {}
-        # Backward from the one row per sequence that carries gradient (class token / EOT): the last block's row-wise
-        # products run on those rows only.  False = scatter the rows into a zero-filled tensor and run every block dense
-        # (identical gradients; kept as the A/B reference, bench.py reports it as a variant).
+        # One row per sequence in the LAST block: the heads read the class token / the EOT token only, so after the last
+        # attention everything is computed for that row alone -- forward (clipfs_tower_fwd_rows: output projection,
+        # LayerNorm 2, MLP) and backward (clipfs_tower_bwd_sparse).  False = every block dense in both directions, the
+        # gradient rows scattered into a zero-filled tensor (identical features and gradients; kept as the A/B
+        # reference, bench.py reports it as a variant).  The name predates the forward half.
         self.sparse_backward = True
 
     @property
@@ -262,7 +271,10 @@ class Engine:
         else:
             x = ops.layernorm_fwd(x0, v.ln_pre.weight.data, v.ln_pre.bias.data)
             mean0 = rstd0 = None
-        saved = self.vis.forward(x, B, train, seed, own_saved=own_saved, row0=row0)
+        # only the class-token row of each image is read below (jclip/model.py:121-124)
+        one_row = bool(self.sparse_backward)
+        saved = self.vis.forward(x, B, train, seed, own_saved=own_saved, row0=row0,
+                                 rows=self._class_rows(B, images.device) if one_row else None)
         if train:
             y, mean1, rstd1 = ops.layernorm_fwd(x, v.ln_post.weight.data, v.ln_post.bias.data, ldx=L * d, rows=B,
                                                 save_stats=True)
@@ -272,7 +284,7 @@ class Engine:
         feat = ops.gemm_nt(y, self.vproj_t)
         ctx = None
         if train:
-            ctx = dict(B=B, x_final=x, saved=saved, stats=(mean1, rstd1), seed=seed, row0=row0,
+            ctx = dict(B=B, x_final=x, saved=saved, stats=(mean1, rstd1), seed=seed, row0=row0, one_row=one_row,
                        pre=(x0, mean0, rstd0) if need_pre else None)
         return feat, ctx
 
@@ -286,7 +298,7 @@ class Engine:
         # and the tower's last block works on B rows (clipfs_tower_bwd_sparse) -- no zero-filled [B*L, width] tensor
         dcls = ops.layernorm_bwd(dy, ctx["x_final"], v.ln_post.weight.data, mean1, rstd1, ldx=L * d)
         has_vpt = v.VPT is not None
-        if self.sparse_backward:
+        if ctx["one_row"]:  # the forward that produced ``saved`` decides (its last block kept one row per image)
             dx = self.vis.backward_sparse(dcls, self._class_rows(B, dfeat.device), B, ctx["saved"], ctx["seed"],
                                           stop_at_input=not has_vpt, row0=ctx["row0"])
         else:
@@ -328,7 +340,10 @@ class Engine:
         ids, seq = self._effective_ids(ids)
         x = ops.text_embed(ids, m.token_embedding.weight.data, m.positional_embedding.data,
                            None if prompt_ctx is None else prompt_ctx.data)
-        saved = self.txt.forward(x, n, train, seed, seq, own_saved=own_saved, row0=row0)
+        # only the EOT row of each caption is read below (jclip/model.py:213-214)
+        one_row = bool(self.sparse_backward)
+        saved = self.txt.forward(x, n, train, seed, seq, own_saved=own_saved, row0=row0,
+                                 rows=ops.eot_index(ids) if one_row else None)
         rows, idx = ops.gather_eot(x, ids)
         if train:
             y, mean, rstd = ops.layernorm_fwd(rows, m.ln_final.weight.data, m.ln_final.bias.data, save_stats=True)
@@ -339,7 +354,7 @@ class Engine:
         ctx = None
         if train:
             ctx = dict(n=n, seq=seq, rows=rows, idx=idx, stats=(mean, rstd), saved=saved, seed=seed, row0=row0,
-                       has_ctx=prompt_ctx is not None)
+                       one_row=one_row, has_ctx=prompt_ctx is not None)
         return feat, ctx
 
     def text_backward(self, ctx: dict, dfeat: torch.Tensor, dctx_slot: Optional[torch.Tensor] = None) -> None:
@@ -349,7 +364,7 @@ class Engine:
         mean, rstd = ctx["stats"]
         drows = ops.layernorm_bwd(dy, ctx["rows"], m.ln_final.weight.data, mean, rstd)
         # only the EOT row of each caption carries gradient (jclip/model.py:213-214)
-        if self.sparse_backward:
+        if ctx["one_row"]:
             dx = self.txt.backward_sparse(drows, ctx["idx"], n, ctx["saved"], ctx["seed"], stop_at_input=not ctx["has_ctx"],
                                           seq=seq, row0=ctx["row0"])
         else:

@@ -253,6 +253,15 @@ def matmul_small(a, b, M, N, K, sam, sak, sbk, sbn, alpha=1.0, out=None):
     return out
 
 
+def eot_index(ids: torch.Tensor) -> torch.Tensor:
+    """idx[c] = position of the EOT token (largest id, first maximum) of caption c, int32 [n] (jclip/model.py:213-214)."""
+    assert ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()
+    n, seq = ids.shape
+    idx = torch.empty(n, device=ids.device, dtype=torch.int32)
+    check(_lib.load().clipfs_eot_index(_p(ids), _p(idx), n, seq, _stream()), "eot_index")
+    return idx
+
+
 def gather_eot(x, ids):
     n, seq = ids.shape
     width = x.shape[-1]

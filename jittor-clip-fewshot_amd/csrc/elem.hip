@@ -113,6 +113,39 @@ __global__ __launch_bounds__(256) void add_seq_rows_kernel(const float* __restri
   }
 }
 
+// dst[(c * seq + idx[c]) * ld + k] = src[c, k]   (the other rows are left alone)
+__global__ __launch_bounds__(256) void put_seq_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                           float* __restrict__ dst, size_t ld, int n, int seq, int width) {
+  const size_t total = (size_t)n * width;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % width), c = (int)(i / width);
+    dst[((size_t)c * seq + idx[c]) * ld + k] = src[i];
+  }
+}
+
+// idx[c] = argmax_l ids[c, l] (first maximum: the EOT token has the largest id, jclip/model.py:213-214)
+__global__ __launch_bounds__(64) void eot_index_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ idx, int n, int seq) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  long best = -1;
+  int at = 0;
+  for (int l = lane; l < seq; l += 64) {
+    const long v = ids[(size_t)c * seq + l];
+    if (v > best) {
+      best = v;
+      at = l;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const long ob = __shfl_xor(best, off, 64);
+    const int oa = __shfl_xor(at, off, 64);
+    if (ob > best || (ob == best && oa < at)) {
+      best = ob;
+      at = oa;
+    }
+  }
+  if (lane == 0) idx[c] = at;
+}
+
 // ---- per class: normalise templates, mean, normalise (lora_train_vlp.py:978-990) ----  one wave per class
 __global__ __launch_bounds__(64) void class_mean_fwd_kernel(const float* __restrict__ emb, float* __restrict__ out,
                                                             int templates, int width) {
@@ -602,6 +635,20 @@ extern "C" int clipfs_add_seq_rows(const float* src, const int32_t* idx, float* 
   CLIPFS_REQUIRE(src && idx && dx && n > 0 && seq > 0 && width > 0, "add_seq_rows: bad args");
   hipLaunchKernelGGL(add_seq_rows_kernel, dim3(grid_for((size_t)n * width)), dim3(256), 0, (hipStream_t)stream, src, idx, dx,
                      n, seq, width);
+  return launch_status();
+}
+
+extern "C" int clipfs_put_seq_rows(const float* src, const int32_t* idx, float* dst, size_t ld, int n, int seq, int width,
+                                   void* stream) {
+  CLIPFS_REQUIRE(src && idx && dst && n > 0 && seq > 0 && width > 0 && ld >= (size_t)width, "put_seq_rows: bad args");
+  hipLaunchKernelGGL(put_seq_rows_kernel, dim3(grid_for((size_t)n * width)), dim3(256), 0, (hipStream_t)stream, src, idx, dst,
+                     ld, n, seq, width);
+  return launch_status();
+}
+
+extern "C" int clipfs_eot_index(const int64_t* ids, int32_t* idx, int n, int seq, void* stream) {
+  CLIPFS_REQUIRE(ids && idx && n > 0 && seq > 0, "eot_index: bad args");
+  hipLaunchKernelGGL(eot_index_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, ids, idx, n, seq);
   return launch_status();
 }
 

@@ -181,7 +181,19 @@ extern "C" size_t clipfs_tower_counter_ints(const clipfs_tower* t, int batch) {
   return scratch_layout(t, (size_t)batch * t->seq).counter_ints;
 }
 
-extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, float* scratch, void* stream) {
+// Last block "one row per sequence" mode (clipfs_tower_fwd_rows / clipfs_tower_bwd_sparse): both directions must agree,
+// the compact forward leaves the skipped rows of x_mid / u / stat2 unwritten.
+static bool last_block_rows_ok(const clipfs_tower* t) {
+  static const bool force_dense = getenv("CLIPFS_DENSE_BWD") && atoi(getenv("CLIPFS_DENSE_BWD")) != 0;  // A/B aid
+  const clipfs_block& b = t->blocks[t->layers - 1];
+  const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
+  return !(force_dense || t->weight_format == 2 || lora_o || t->seq < 8);
+}
+
+// rows == NULL: every row of every block.  rows != NULL (and last_block_rows_ok): the LAST block's output projection,
+// LayerNorm 2 and MLP run on the `batch` rows c * seq + rows[c] only.
+static int tower_fwd_impl(const clipfs_tower* t, float* x, const int32_t* rows, int batch, float* saved, float* scratch,
+                          void* stream) {
   CLIPFS_CHECK(check_tower(t, batch));
   CLIPFS_REQUIRE(x && scratch, "tower_fwd: null buffer");
   hipStream_t st = (hipStream_t)stream;
@@ -236,6 +248,40 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
       att16 = h16;
     } else
       CLIPFS_CHECK(clipfs_attention_fwd(qkv, att, train ? sv + SL.lse : nullptr, batch, t->seq, t->heads, t->causal, st));
+    if (rows && l == t->layers - 1) {
+      // ---- the rest of the LAST block on one row per sequence: the head reads nothing else (jclip/model.py:121-124,
+      // :213-214) and every remaining operation is row-wise.  Compact buffers live in the MLP scratch (Ms (13 d + 2)
+      // floats <= M 4 d for seq >= 4); what the sparse backward gathers (x_mid, u, LayerNorm-2 statistics) is put back
+      // at those rows of the saved tensors, the block output at those rows of x.
+      const int seq = t->seq, Ms = batch;
+      float* att_s = scratch + SC.big;
+      float* xin_s = att_s + (size_t)Ms * d;
+      float* xmid_s = xin_s + (size_t)Ms * d;
+      float* h2_s = xmid_s + (size_t)Ms * d;
+      float* xout_s = h2_s + (size_t)Ms * d;
+      float* g_s = xout_s + (size_t)Ms * d;
+      float* u_s = g_s + (size_t)Ms * 4 * d;
+      float* mean_s = u_s + (size_t)Ms * 4 * d;
+      float* rstd_s = mean_s + al4((size_t)Ms);
+      CLIPFS_CHECK(clipfs_gather_seq_rows(att, (size_t)d, rows, att_s, Ms, seq, d, st));
+      CLIPFS_CHECK(clipfs_gather_seq_rows(x_in, (size_t)d, rows, xin_s, Ms, seq, d, st));
+      CLIPFS_CHECK(gemm(cx, att_s, b.w_o, b.w_o_p, xmid_s, Ms, d, d, b.b_o, xin_s, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
+                        st));
+      CLIPFS_CHECK(clipfs_layernorm_fwd(xmid_s, d, b.ln2_g, b.ln2_b, h2_s, train ? mean_s : nullptr, train ? rstd_s : nullptr, Ms,
+                                        d, 1e-5f, st));
+      CLIPFS_CHECK(gemm(cx, h2_s, b.w_fc, b.w_fc_p, g_s, Ms, 4 * d, d, b.b_fc, nullptr, 1, train ? u_s : nullptr, nullptr, nullptr,
+                        nullptr, 0, 0, 0, 0.f, st));
+      CLIPFS_CHECK(gemm(cx, g_s, b.w_pr, b.w_pr_p, xout_s, Ms, d, 4 * d, b.b_pr, xmid_s, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+                        0.f, st));
+      CLIPFS_CHECK(clipfs_put_seq_rows(xout_s, rows, x, (size_t)d, Ms, seq, d, st));
+      if (train) {
+        CLIPFS_CHECK(clipfs_put_seq_rows(xmid_s, rows, sv + SL.x_mid, (size_t)d, Ms, seq, d, st));
+        CLIPFS_CHECK(clipfs_put_seq_rows(u_s, rows, sv + SL.u, (size_t)4 * d, Ms, seq, 4 * d, st));
+        CLIPFS_CHECK(clipfs_put_seq_rows(mean_s, rows, sv + SL.stat2, 1, Ms, seq, 1, st));
+        CLIPFS_CHECK(clipfs_put_seq_rows(rstd_s, rows, sv + SL.stat2 + M, 1, Ms, seq, 1, st));
+      }
+      break;
+    }
     if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, t->dropout_row0, st));
     CLIPFS_CHECK(gemm(cx, att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
                       1, d, t->lora_scale, st, CHAIN_NONE, att16));
@@ -253,6 +299,21 @@ extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, floa
                       0.f, st, CHAIN_IN16));
   }
   return CLIPFS_OK;
+}
+
+extern "C" int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, float* scratch, void* stream) {
+  return tower_fwd_impl(t, x, nullptr, batch, saved, scratch, stream);
+}
+
+extern "C" int clipfs_tower_fwd_rows(const clipfs_tower* t, float* x, const int32_t* rows, int batch, float* saved,
+                                     float* scratch, void* stream) {
+  CLIPFS_REQUIRE(t && rows, "tower_fwd_rows: null argument");
+  CLIPFS_CHECK(check_tower(t, batch));
+  return tower_fwd_impl(t, x, last_block_rows_ok(t) ? rows : nullptr, batch, saved, scratch, stream);
+}
+
+extern "C" int clipfs_tower_rows_mode(const clipfs_tower* t) {
+  return (t && t->blocks && t->layers > 0 && last_block_rows_ok(t)) ? 1 : 0;
 }
 
 // blocks l_hi ... 0 of the backward; dx [batch*seq, width] in/out
@@ -354,9 +415,7 @@ extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, 
                  "tower: gemm_counters holds %zu ints, %zu needed", t->gemm_counters_ints, SC.counter_ints);
   const int l = t->layers - 1;
   const clipfs_block& b = t->blocks[l];
-  const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
-  static const bool force_dense = getenv("CLIPFS_DENSE_BWD") && atoi(getenv("CLIPFS_DENSE_BWD")) != 0;  // A/B aid
-  if (force_dense || t->weight_format == 2 || lora_o || seq < 8) {  // dense fall-back: the row gradients scattered into zeros
+  if (!last_block_rows_ok(t)) {  // dense fall-back: the row gradients scattered into zeros
     CLIPFS_CHECK(clipfs_scatter_rows(dxs, rows, dx, batch, seq, d, st));
     return tower_bwd_range(t, dx, batch, saved, scratch, stop_at_input, st, l);
   }

@@ -701,13 +701,29 @@ def test_sparse_and_dense_backward_agree(dev, monkeypatch):
         img = synth.synth_images(B, cfg.image_resolution, seed=3).to(dev)
         cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=4, max_len=12).to(dev)
         tgt = synth.synth_labels(B, Cn, seed=2).to(dev)
-        got = {}
+        got, logits = {}, {}
         for sparse in (True, False):
             model.engine.sparse_backward = sparse
             model.engine.step = 0  # same dropout seed for both passes
             tr.flat.zero_grad()
-            tr.forward_backward(img, cap, tgt)
+            _, _, lg = tr.forward_backward(img, cap, tgt)
             got[sparse] = tr.flat.grads.clone()
+            logits[sparse] = lg.clone()
         scale = got[False].abs().max().item()
         assert scale > 1e-4
         assert (got[True] - got[False]).abs().max().item() < 2e-6 * scale + 1e-9, params
+        # the forward half (last block's out-proj / LayerNorm 2 / MLP on the class / EOT rows only): same logits
+        assert (logits[True] - logits[False]).abs().max().item() < 2e-5, params
+        # and the no-grad route (eval, TTA) reads the same features either way
+        model.eval()
+        feats = {}
+        for sparse in (True, False):
+            model.engine.sparse_backward = sparse
+            with torch.no_grad():
+                fi, _ = model.engine.vit_forward(img, False)
+                ft, _ = model.engine.text_forward(cap, ctx_param, False)
+            feats[sparse] = (fi.clone(), ft.clone())
+        for a, b in zip(feats[True], feats[False]):
+            assert (a - b).abs().max().item() < 2e-6 * b.abs().max().item() + 1e-7, params
+        model.train()
+        model.engine.sparse_backward = True
