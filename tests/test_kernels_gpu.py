@@ -466,6 +466,43 @@ def test_gemm_f16_phased_kernel_is_deterministic_and_matches_two_phase():
             assert (first[r0:r0 + 8192] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
 
 
+@pytest.mark.gpu
+def test_seq_row_helpers_and_eot_index():
+    """One-row-per-sequence building blocks of clipfs_tower_fwd_rows / clipfs_tower_bwd_sparse through the C ABI: gather,
+    put (other rows untouched), add, and the EOT position (argmax of the ids, first maximum: jclip/model.py:213-214)."""
+    import ctypes as C
+    from clipfs import _lib, ops
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    n, seq, width, ld = 37, 11, 20, 28
+    src = torch.randn(n * seq, ld, generator=g).cuda()
+    idx = torch.randint(0, seq, (n,), generator=g, dtype=torch.int32).cuda()
+    flat = (torch.arange(n, device="cuda") * seq + idx.long())
+    out = torch.empty(n, width, device="cuda")
+    _lib.check(lib.clipfs_gather_seq_rows(src.data_ptr(), ld, idx.data_ptr(), out.data_ptr(), n, seq, width, st), "gather")
+    assert torch.equal(out, src[flat, :width])
+    dst = torch.randn(n * seq, ld, generator=g).cuda()
+    want = dst.clone()
+    want[flat, :width] = out
+    _lib.check(lib.clipfs_put_seq_rows(out.data_ptr(), idx.data_ptr(), dst.data_ptr(), ld, n, seq, width, st), "put")
+    assert torch.equal(dst, want)
+    dx = torch.randn(n * seq, width, generator=g).cuda()
+    want = dx.clone()
+    want[flat] += out
+    _lib.check(lib.clipfs_add_seq_rows(out.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, seq, width, st), "add")
+    assert torch.equal(dx, want)
+    # EOT index: ties (two copies of the largest id) resolve to the first, as argmax does in the reference
+    ids = torch.randint(1, 1000, (53, 77), generator=g, dtype=torch.int64)
+    pos = torch.randint(1, 77, (53,), generator=g)
+    ids[torch.arange(53), pos] = 49407
+    ids[5, 70] = 49407
+    ids[5, 3] = 49407
+    got = ops.eot_index(ids.cuda())
+    assert got.dtype == torch.int32 and torch.equal(got.cpu().long(), ids.argmax(dim=-1))
+    assert got[5].item() == min(3, int(pos[5]))
+
+
 def _attn_ref64(qkv, batch, seq, heads, causal=False):
     d = heads * 64
     x = qkv.double().view(batch, seq, 3, heads, 64)
