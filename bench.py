@@ -57,6 +57,9 @@ TXT_BWD_ZERO = 9 * 512 * 512 * 2 * 76 / 1e9
 # The forward has the same structure: after the last attention nothing but the class / EOT row is ever read, so the last
 # block's output projection, LayerNorm 2 and MLP (the same 9 d^2 MACs per token) run on that row (clipfs_tower_fwd_rows):
 IMG_FWD_ZERO, TXT_FWD_ZERO = IMG_BWD_ZERO, TXT_BWD_ZERO
+# the same rows of ViT-L/14 (cfg-5: width 1024 / 257 tokens, text width 768 / 77 tokens), forward + backward together
+L14_IMG_ZERO = 2 * 9 * 1024 * 1024 * 2 * 256 / 1e9
+L14_TXT_ZERO = 2 * 9 * 768 * 768 * 2 * 76 / 1e9
 
 
 def parse():
@@ -468,7 +471,9 @@ def main():
     if rank == 0:
         n_img_local = hi - lo
         if args.model == "l14":  # 162.03 (+0.303 LoRA) per image, 13.30 per caption; dgrad ~= forward
-            step_tflop = (gb * 2 * (162.03 + 0.303) + args.classes * 2 * 13.30) / 1e3
+            dense_bwd = os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
+            step_tflop = (gb * (2 * (162.03 + 0.303) - (0 if dense_bwd else L14_IMG_ZERO)) +
+                          args.classes * (2 * 13.30 - (0 if dense_bwd else L14_TXT_ZERO))) / 1e3
         elif args.forward_only:
             dense_bwd = os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
             step_tflop = gb * (IMG_FWD - (0 if dense_bwd else IMG_FWD_ZERO)) / 1e3
@@ -593,7 +598,7 @@ def cfg5_leg(dev, args, lib):
     torch.cuda.synchronize()
     lib.clipfs_gemm_timing(0)
     roof = collect_roofline(lib, args, "fp16")
-    step_tflop = (B * 2 * (162.03 + 0.303) + 403 * 2 * 13.30) / 1e3
+    step_tflop = (B * (2 * (162.03 + 0.303) - L14_IMG_ZERO) + 403 * (2 * 13.30 - L14_TXT_ZERO)) / 1e3
     print(f"[bench] cfg5 leg: {dt * 1e3:.1f} ms/step ({time.time() - t0:.0f} s incl. model build)", file=sys.stderr, flush=True)
     return {"workload": "cfg-5 shapes on ONE GPU: ViT-L/14 + rank-16 LoRA (synthetic adapters), fp16 storage mode, 128 images "
                         "(one rank's share of bs 1024) + 403 captions, train step; 6 steps after 3 warm-ups",

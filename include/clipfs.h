@@ -234,6 +234,12 @@ int clipfs_add_seq_rows(const float* src, const int32_t* idx, float* dx, int n, 
 int clipfs_put_seq_rows(const float* src, const int32_t* idx, float* dst, size_t ld, int n, int seq, int width,
                         void* stream);
 int clipfs_eot_index(const int64_t* ids, int32_t* idx, int n, int seq, void* stream);
+/* gather / put for a tensor kept as f16 (the saved pre-GELU activation of the fp16 storage mode); ld in halves, the
+ * compact side [n, width] is fp32 */
+int clipfs_gather_seq_rows_f16(const void* src_f16, size_t ld, const int32_t* idx, float* out, int n, int seq, int width,
+                               void* stream);
+int clipfs_put_seq_rows_f16(const float* src, const int32_t* idx, void* dst_f16, size_t ld, int n, int seq, int width,
+                            void* stream);
 
 /* --------------------------------------------------------- BPE tokenizer --
  * Native merge loop of the CLIP byte-pair encoder (jclip/simple_tokenizer.py:88-129; host code, no GPU work).
@@ -373,8 +379,9 @@ int clipfs_tower_fwd(const clipfs_tower* t, float* x, int batch, float* saved, f
  * token, 5.9 % of the image tower's forward and 6.0 % of the text tower's at cfg-2.  On return x holds the block output
  * at rows c*seq + rows[c] ONLY (the other rows keep the last block's input); `saved` is complete for
  * clipfs_tower_bwd_sparse with the same rows and NOT for clipfs_tower_bwd.  Falls back to clipfs_tower_fwd in the
- * cases clipfs_tower_bwd_sparse falls back (clipfs_tower_rows_mode() == 0: fp16 storage mode, an o-projection adapter
- * in the last block, seq < 8, CLIPFS_DENSE_BWD=1), so the two always agree. */
+ * cases clipfs_tower_bwd_sparse falls back (clipfs_tower_rows_mode() == 0: an o-projection adapter in the last block,
+ * seq < 8, CLIPFS_DENSE_BWD=1), so the two always agree.  In the fp16 storage mode the `batch`-row products use the
+ * fp32 master weights. */
 int clipfs_tower_fwd_rows(const clipfs_tower* t, float* x, const int32_t* rows, int batch, float* saved, float* scratch,
                           void* stream);
 int clipfs_tower_rows_mode(const clipfs_tower* t);
@@ -389,7 +396,7 @@ int clipfs_tower_bwd(const clipfs_tower* t, float* dx, int batch, const float* s
  * zero-filled input needed) with the gradient wrt the tower input.  In the LAST block the MLP and output-projection
  * input-gradients are row-wise, so they run on `batch` rows instead of batch*seq (exact: the skipped rows are exact
  * zeros): 9 d^2 MACs per skipped token, 1.4 % (image) + 1.6 % (text) of the cfg-2 step.  Falls back to the dense path
- * (scatter + clipfs_tower_bwd) for the fp16 storage mode, o-projection adapters in the last block and seq < 8. */
+ * (scatter + clipfs_tower_bwd) for o-projection adapters in the last block and seq < 8 (clipfs_tower_rows_mode). */
 int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, const int32_t* rows, float* dx, int batch,
                             const float* saved, float* scratch, int stop_at_input, void* stream);
 

@@ -101,6 +101,8 @@ SIGNATURES = {
     "clipfs_add_seq_rows": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "clipfs_put_seq_rows": (_i, [_p, _p, _p, _sz, _i, _i, _i, _p]),
     "clipfs_eot_index": (_i, [_p, _p, _i, _i, _p]),
+    "clipfs_gather_seq_rows_f16": (_i, [_p, _sz, _p, _p, _i, _i, _i, _p]),
+    "clipfs_put_seq_rows_f16": (_i, [_p, _p, _p, _sz, _i, _i, _i, _p]),
     "clipfs_l2norm_fwd": (_i, [_p, _p, _p, _i, _i, _p]),
     "clipfs_l2norm_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "clipfs_class_mean_fwd": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -123,6 +123,25 @@ __global__ __launch_bounds__(256) void put_seq_rows_kernel(const float* __restri
   }
 }
 
+// the same two for a tensor stored as f16 (fp16 storage mode: the saved pre-GELU activation); the compact side stays fp32
+__global__ __launch_bounds__(256) void gather_seq_rows_f16_kernel(const _Float16* __restrict__ src, size_t ld,
+                                                                  const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                                  int n, int seq, int width) {
+  const size_t total = (size_t)n * width;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % width), c = (int)(i / width);
+    out[i] = (float)src[((size_t)c * seq + idx[c]) * ld + k];
+  }
+}
+__global__ __launch_bounds__(256) void put_seq_rows_f16_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                               _Float16* __restrict__ dst, size_t ld, int n, int seq, int width) {
+  const size_t total = (size_t)n * width;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % width), c = (int)(i / width);
+    dst[((size_t)c * seq + idx[c]) * ld + k] = (_Float16)src[i];
+  }
+}
+
 // idx[c] = argmax_l ids[c, l] (first maximum: the EOT token has the largest id, jclip/model.py:213-214)
 __global__ __launch_bounds__(64) void eot_index_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ idx, int n, int seq) {
   const int c = blockIdx.x, lane = threadIdx.x;
@@ -643,6 +662,22 @@ extern "C" int clipfs_put_seq_rows(const float* src, const int32_t* idx, float* 
   CLIPFS_REQUIRE(src && idx && dst && n > 0 && seq > 0 && width > 0 && ld >= (size_t)width, "put_seq_rows: bad args");
   hipLaunchKernelGGL(put_seq_rows_kernel, dim3(grid_for((size_t)n * width)), dim3(256), 0, (hipStream_t)stream, src, idx, dst,
                      ld, n, seq, width);
+  return launch_status();
+}
+
+extern "C" int clipfs_gather_seq_rows_f16(const void* src_f16, size_t ld, const int32_t* idx, float* out, int n, int seq,
+                                          int width, void* stream) {
+  CLIPFS_REQUIRE(src_f16 && idx && out && n > 0 && seq > 0 && width > 0 && ld >= (size_t)width, "gather_seq_rows_f16: bad args");
+  hipLaunchKernelGGL(gather_seq_rows_f16_kernel, dim3(grid_for((size_t)n * width)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const _Float16*>(src_f16), ld, idx, out, n, seq, width);
+  return launch_status();
+}
+
+extern "C" int clipfs_put_seq_rows_f16(const float* src, const int32_t* idx, void* dst_f16, size_t ld, int n, int seq,
+                                       int width, void* stream) {
+  CLIPFS_REQUIRE(src && idx && dst_f16 && n > 0 && seq > 0 && width > 0 && ld >= (size_t)width, "put_seq_rows_f16: bad args");
+  hipLaunchKernelGGL(put_seq_rows_f16_kernel, dim3(grid_for((size_t)n * width)), dim3(256), 0, (hipStream_t)stream, src, idx,
+                     reinterpret_cast<_Float16*>(dst_f16), ld, n, seq, width);
   return launch_status();
 }
 

@@ -187,7 +187,7 @@ static bool last_block_rows_ok(const clipfs_tower* t) {
   static const bool force_dense = getenv("CLIPFS_DENSE_BWD") && atoi(getenv("CLIPFS_DENSE_BWD")) != 0;  // A/B aid
   const clipfs_block& b = t->blocks[t->layers - 1];
   const bool lora_o = b.lora_a_o && (b.lora_mask & 8u);
-  return !(force_dense || t->weight_format == 2 || lora_o || t->seq < 8);
+  return !(force_dense || lora_o || t->seq < 8);
 }
 
 // rows == NULL: every row of every block.  rows != NULL (and last_block_rows_ok): the LAST block's output projection,
@@ -265,18 +265,24 @@ static int tower_fwd_impl(const clipfs_tower* t, float* x, const int32_t* rows, 
       float* rstd_s = mean_s + al4((size_t)Ms);
       CLIPFS_CHECK(clipfs_gather_seq_rows(att, (size_t)d, rows, att_s, Ms, seq, d, st));
       CLIPFS_CHECK(clipfs_gather_seq_rows(x_in, (size_t)d, rows, xin_s, Ms, seq, d, st));
-      CLIPFS_CHECK(gemm(cx, att_s, b.w_o, b.w_o_p, xmid_s, Ms, d, d, b.b_o, xin_s, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
-                        st));
+      // fp16 storage mode: these `batch`-row products use the fp32 master weights (plane argument NULL) -- the f16 kernels
+      // are built for tens of thousands of rows -- and the pre-GELU rows go back into the f16 tensor the dense path keeps
+      const bool f16m = t->weight_format == 2;
+      CLIPFS_CHECK(gemm(cx, att_s, b.w_o, f16m ? nullptr : b.w_o_p, xmid_s, Ms, d, d, b.b_o, xin_s, 0, nullptr, nullptr, nullptr, nullptr,
+                        0, 0, 0, 0.f, st));
       CLIPFS_CHECK(clipfs_layernorm_fwd(xmid_s, d, b.ln2_g, b.ln2_b, h2_s, train ? mean_s : nullptr, train ? rstd_s : nullptr, Ms,
                                         d, 1e-5f, st));
-      CLIPFS_CHECK(gemm(cx, h2_s, b.w_fc, b.w_fc_p, g_s, Ms, 4 * d, d, b.b_fc, nullptr, 1, train ? u_s : nullptr, nullptr, nullptr,
+      CLIPFS_CHECK(gemm(cx, h2_s, b.w_fc, f16m ? nullptr : b.w_fc_p, g_s, Ms, 4 * d, d, b.b_fc, nullptr, 1, train ? u_s : nullptr,
+                        nullptr, nullptr, nullptr, 0, 0, 0, 0.f, st));
+      CLIPFS_CHECK(gemm(cx, g_s, b.w_pr, f16m ? nullptr : b.w_pr_p, xout_s, Ms, d, 4 * d, b.b_pr, xmid_s, 0, nullptr, nullptr, nullptr,
                         nullptr, 0, 0, 0, 0.f, st));
-      CLIPFS_CHECK(gemm(cx, g_s, b.w_pr, b.w_pr_p, xout_s, Ms, d, 4 * d, b.b_pr, xmid_s, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
-                        0.f, st));
       CLIPFS_CHECK(clipfs_put_seq_rows(xout_s, rows, x, (size_t)d, Ms, seq, d, st));
       if (train) {
         CLIPFS_CHECK(clipfs_put_seq_rows(xmid_s, rows, sv + SL.x_mid, (size_t)d, Ms, seq, d, st));
-        CLIPFS_CHECK(clipfs_put_seq_rows(u_s, rows, sv + SL.u, (size_t)4 * d, Ms, seq, 4 * d, st));
+        if (f16m)
+          CLIPFS_CHECK(clipfs_put_seq_rows_f16(u_s, rows, sv + SL.u, (size_t)4 * d, Ms, seq, 4 * d, st));
+        else
+          CLIPFS_CHECK(clipfs_put_seq_rows(u_s, rows, sv + SL.u, (size_t)4 * d, Ms, seq, 4 * d, st));
         CLIPFS_CHECK(clipfs_put_seq_rows(mean_s, rows, sv + SL.stat2, 1, Ms, seq, 1, st));
         CLIPFS_CHECK(clipfs_put_seq_rows(rstd_s, rows, sv + SL.stat2 + M, 1, Ms, seq, 1, st));
       }
@@ -433,17 +439,23 @@ extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, 
   float* mean_s = datt_s + (size_t)Ms * d;
   float* rstd_s = mean_s + al4((size_t)Ms);
   // ---- MLP and output projection on the `batch` rows that carry gradient ----
-  CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.u, (size_t)4 * d, rows, u_s, Ms, seq, 4 * d, st));
+  // fp16 storage mode: the `batch`-row products use the fp32 master weights (plane argument NULL); the saved pre-GELU
+  // activation is an f16 tensor there
+  const bool f16m = t->weight_format == 2;
+  if (f16m)
+    CLIPFS_CHECK(clipfs_gather_seq_rows_f16(sv + SL.u, (size_t)4 * d, rows, u_s, Ms, seq, 4 * d, st));
+  else
+    CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.u, (size_t)4 * d, rows, u_s, Ms, seq, 4 * d, st));
   CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.x_mid, (size_t)d, rows, xmid_s, Ms, seq, d, st));
   CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.stat2, 1, rows, mean_s, Ms, seq, 1, st));
   CLIPFS_CHECK(clipfs_gather_seq_rows(sv + SL.stat2 + M, 1, rows, rstd_s, Ms, seq, 1, st));
-  CLIPFS_CHECK(gemm(cx, dxs, b.w_pr_t, b.w_pr_t_p, du_s, Ms, 4 * d, d, nullptr, nullptr, 2, nullptr, u_s, nullptr, nullptr, 0, 0, 0,
-                    0.f, st));
-  CLIPFS_CHECK(gemm(cx, du_s, b.w_fc_t, b.w_fc_t_p, dh_s, Ms, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
-                    0.f, st));
+  CLIPFS_CHECK(gemm(cx, dxs, b.w_pr_t, f16m ? nullptr : b.w_pr_t_p, du_s, Ms, 4 * d, d, nullptr, nullptr, 2, nullptr, u_s, nullptr, nullptr,
+                    0, 0, 0, 0.f, st));
+  CLIPFS_CHECK(gemm(cx, du_s, b.w_fc_t, f16m ? nullptr : b.w_fc_t_p, dh_s, Ms, d, 4 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                    nullptr, 0, 0, 0, 0.f, st));
   CLIPFS_CHECK(clipfs_layernorm_bwd(dh_s, xmid_s, d, b.ln2_g, mean_s, rstd_s, dxs, dxm_s, d, Ms, d, st));
-  CLIPFS_CHECK(gemm(cx, dxm_s, b.w_o_t, b.w_o_t_p, datt_s, Ms, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
-                    0.f, st));
+  CLIPFS_CHECK(gemm(cx, dxm_s, b.w_o_t, f16m ? nullptr : b.w_o_t_p, datt_s, Ms, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                    nullptr, 0, 0, 0, 0.f, st));
   // ---- attention and the QKV projection see every row again ----
   float* dh = scratch + SC.h;
   float* datt = scratch + SC.b1;
@@ -451,13 +463,20 @@ extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, 
   float* dt = scratch + SC.dt;
   float* work = scratch + SC.work;
   CLIPFS_CHECK(clipfs_scatter_rows(datt_s, rows, datt, batch, seq, d, st));
-  CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, seq, t->heads, t->causal, st));
+  const void* dqkv16_ready = nullptr;
+  if (f16_attention(t)) {
+    void* dqkv16 = cx.a16 ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves (tower_bwd_range's slot)
+    CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dqkv, dqkv16, dh, batch, seq,
+                                          t->heads, t->causal, st));
+    dqkv16_ready = dqkv16;
+  } else
+    CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, seq, t->heads, t->causal, st));
   const unsigned qkv_mask = b.lora_a_qkv ? (b.lora_mask & 7u) : 0u;
   const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
   const bool need_dx = !(l == 0 && stop_at_input);
   if (need_dx)
     CLIPFS_CHECK(gemm(cx, dqkv, b.w_qkv_t, b.w_qkv_t_p, dh, M, d, 3 * d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0,
-                      0, 0.f, st));
+                      0, 0.f, st, CHAIN_NONE, dqkv16_ready));
   if (qkv_mask) {
     CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);
     CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv, b.g_lora_b_qkv,

@@ -474,6 +474,16 @@ def test_fp16_precision_mode_l14(dev, monkeypatch):
     # LoRA / prompt gradients of the fp16 path (f16 GEMM operands, f16 MFMA attention fwd + bwd) against the exact
     # fp32 path: 3e-2 of the largest entry
     assert (g16 - g32).abs().max().item() < 3e-2 * g32.abs().max().item()
+    # the last block on one row per sequence (default; its compact products run on the fp32 master weights) against the
+    # all-rows fp16 path: same logits and gradients to fp16 accuracy
+    model.engine.sparse_backward = False
+    tr.flat.zero_grad()
+    _, _, logits_dense = tr.forward_backward(img.to(dev), cap.to(dev), tgt.to(dev))
+    g16d = tr.flat.grads.clone()
+    model.engine.sparse_backward = True
+    assert _err(logits_dense, wl) < 5e-2
+    assert (logits_dense - logits).abs().max().item() < 2e-2
+    assert (g16 - g16d).abs().max().item() < 1e-2 * g32.abs().max().item()
 
 
 def test_fp16_step_at_cfg5_row_counts_is_bitwise_reproducible(dev, monkeypatch):
