@@ -33,7 +33,12 @@ extern "C" {
 #define CLIPFS_EINVAL 1
 #define CLIPFS_HIPERR_BASE 1000
 
-#define CLIPFS_ABI_VERSION 1
+/* Version 2 (round 3): the descriptor structs (clipfs_gemm_args, clipfs_tower) start with `struct_size` = sizeof of the
+ * struct the CALLER was compiled against; the library rejects (CLIPFS_EINVAL, nothing launched) a size it does not know
+ * instead of reading fields at shifted offsets.  New fields are appended at the END of a struct only; a change that moves
+ * an existing field or a parameter of an entry point bumps this number.  Version 1 (rounds 1-2) had no size member and
+ * changed layout once without a bump: binaries built against it must be rebuilt. */
+#define CLIPFS_ABI_VERSION 2
 int clipfs_abi_version(void);
 /* sha256 prefixes (16 hex digits) of the sources the library was built from: all of csrc/ + this header, and the
  * fp32 GEMM alone (gemm.hip, gemm_common.h, common.h).  "unstamped" when built without build.py. */
@@ -64,6 +69,7 @@ const char* clipfs_last_error(void);
  *           class-token slot skipped, positional embedding added (model.py:105-114).
  */
 typedef struct clipfs_gemm_args {
+  size_t struct_size;      /* = sizeof(clipfs_gemm_args) of the caller's header (ABI check) */
   const float* A;
   const float* B;          /* [N,K] row-major, ldb */
   float* C;                /* [*,N] row-major, ldc */
@@ -353,6 +359,8 @@ typedef struct clipfs_block {
 } clipfs_block;
 
 typedef struct clipfs_tower {
+  size_t struct_size;       /* = sizeof(clipfs_tower) of the caller's header (ABI check) */
+  size_t block_size;        /* = sizeof(clipfs_block): the stride of `blocks` */
   int width, heads, layers, seq, causal;
   int lora_r;
   float lora_scale, lora_dropout;

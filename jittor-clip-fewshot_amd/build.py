@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "clipfs", "libclipfs_hip.so")
 SOURCES = ["common.hip", "gemm.hip", "gemm_bf16.hip", "gemm_f16.hip", "norm.hip", "attention.hip", "attention_f16.hip", "attention_mfma.hip", "attention_mfma16.hip", "lora.hip", "lora_mfma.hip", "elem.hip", "mta.hip", "views.hip", "resnet.hip", "bpe.hip", "tower.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC, "-Wall",
-         "-Wno-unused-function", "-ffp-contract=off"]
+         "-Wno-unused-function", "-ffp-contract=off"] + os.environ.get("HIPCC_EXTRA", "").split()
 
 
 def _newer(target: str, deps) -> bool:

@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+ABI_VERSION = 2  # CLIPFS_ABI_VERSION of include/clipfs.h this table was written against
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libclipfs_hip.so")
 
@@ -22,6 +24,7 @@ class ClipfsError(RuntimeError):
 
 class GemmArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_size_t),
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
@@ -52,6 +55,7 @@ class Block(C.Structure):
 
 class Tower(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_size_t), ("block_size", C.c_size_t),
         ("width", C.c_int), ("heads", C.c_int), ("layers", C.c_int), ("seq", C.c_int), ("causal", C.c_int),
         ("lora_r", C.c_int), ("lora_scale", C.c_float), ("lora_dropout", C.c_float),
         ("dropout_seed", C.c_uint64), ("dropout_stream0", C.c_uint32), ("dropout_row0", C.c_uint32),
@@ -136,6 +140,19 @@ SIGNATURES = {
     "clipfs_tower_bwd_sparse": (_i, [C.POINTER(Tower), _p, _p, _p, _i, _p, _p, _i, _p]),
 }
 
+def new_gemm_args() -> GemmArgs:
+    g = GemmArgs()
+    g.struct_size = C.sizeof(GemmArgs)
+    return g
+
+
+def new_tower() -> Tower:
+    t = Tower()
+    t.struct_size = C.sizeof(Tower)
+    t.block_size = C.sizeof(Block)
+    return t
+
+
 _lib = None
 
 
@@ -158,8 +175,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.clipfs_abi_version() != 1:
-        raise ClipfsError("libclipfs_hip.so ABI version mismatch")
+    if lib.clipfs_abi_version() != ABI_VERSION:
+        raise ClipfsError(f"libclipfs_hip.so ABI version {lib.clipfs_abi_version()} != {ABI_VERSION} of this binding: "
+                          "rebuild with `python jittor-clip-fewshot_amd/build.py --force`")
     _lib = lib
     return lib
 

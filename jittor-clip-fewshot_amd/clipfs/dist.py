@@ -67,6 +67,11 @@ def allgather_blocks(block: torch.Tensor, out: Optional[torch.Tensor] = None, gr
     _, world = world_info(group)
     if out is None:
         out = torch.empty(world * block.shape[0], block.shape[1], device=block.device, dtype=block.dtype)
+    # the collectives take flat buffers: a wrong shape or a strided view would be exchanged silently
+    if block.dim() != 2 or out.shape != (world * block.shape[0], block.shape[1]) or out.dtype != block.dtype:
+        raise ValueError(f"allgather_blocks: block {tuple(block.shape)} x world {world} does not fill out {tuple(out.shape)}")
+    if not (block.is_contiguous() and out.is_contiguous()):
+        raise ValueError("allgather_blocks: send block and result must be contiguous")
     if _live(world):
         dist.all_gather_into_tensor(out, block, group=group)
     else:
@@ -77,9 +82,15 @@ def allgather_blocks(block: torch.Tensor, out: Optional[torch.Tensor] = None, gr
 def reduce_scatter_blocks(full: torch.Tensor, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
     """``full`` [world * S, w] (every rank's partial sums for ALL rows) -> this rank's [S, w] block of the total."""
     rank, world = world_info(group)
+    if full.dim() != 2 or full.shape[0] % world != 0:
+        raise ValueError(f"reduce_scatter_blocks: {tuple(full.shape)} is not world {world} x [S, w]")
     s = full.shape[0] // world
     if out is None:
         out = torch.empty(s, full.shape[1], device=full.device, dtype=full.dtype)
+    if out.shape != (s, full.shape[1]) or out.dtype != full.dtype:
+        raise ValueError(f"reduce_scatter_blocks: out {tuple(out.shape)} is not the [S = {s}, {full.shape[1]}] block")
+    if not (full.is_contiguous() and out.is_contiguous()):
+        raise ValueError("reduce_scatter_blocks: table and result must be contiguous")
     if _live(world):
         dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=group)
     else:

@@ -112,7 +112,7 @@ class _TowerRT:
                 if a.lora_mask & 8:
                     b.lora_a_o, b.lora_b_o = _ptr(a.lora_A_o), _ptr(a.lora_B_o)
                     b.g_lora_a_o, b.g_lora_b_o = _ptr(a.grad_A_o), _ptr(a.grad_B_o)
-        t = Tower()
+        t = _lib.new_tower()
         t.width, t.heads, t.layers, t.seq, t.causal = (self.width, self.heads, self.layers, seq or self.seq,
                                                        int(self.causal))
         t.lora_r, t.lora_scale, t.lora_dropout = r, scale, p
@@ -126,6 +126,10 @@ class _TowerRT:
         t._blocks_keepalive = blocks  # ctypes array must outlive the call
         self.lora_r, self.lora_scale, self.lora_dropout = r, scale, p
         return t
+
+    def lora_dropout_rate(self) -> float:
+        return max((float(b.attn.dropout_rate) for b in self.mod.resblocks
+                    if getattr(b.attn, "is_lora_mha", False) and b.attn.r > 0), default=0.0)
 
     def has_lora(self) -> bool:
         return any(getattr(b.attn, "is_lora_mha", False) and b.attn.r > 0 for b in self.mod.resblocks)
@@ -218,7 +222,9 @@ class Engine:
         self.step = 0
         # Optional (off by default): run the text tower only on positions <= the last EOT of the batch.  Under the
         # causal mask nothing after a caption's EOT can influence its EOT feature, nor receive gradient from it, so
-        # the reference's rows EOT+1..76 (jclip/model.py:202-215 encodes all 77) are dead work.
+        # the reference's rows EOT+1..76 (jclip/model.py:202-215 encodes all 77) are dead work.  With LoRA dropout the
+        # masks are indexed by token row = caption * (trimmed seq) + position: a trimmed run draws a different (equally
+        # valid) mask stream than the untrimmed one, and LoRATrainer refuses trim_text + class-sharded text + dropout.
         self.trim_text = False
         self._trim_cache = {}
         # One row per sequence in the LAST block: the heads read the class token / the EOT token only, so after the last

@@ -56,7 +56,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     assert b.shape[1] == K
     if out is None and not only16:
         out = torch.empty(M, N, device=b.device, dtype=torch.float32)
-    g = GemmArgs()
+    g = _lib.new_gemm_args()
     g.A, g.B, g.C = _p(a), _p(b), (None if only16 else _p(out))
     if a16 is not None:
         assert a16.dtype == torch.float16 and a16.is_contiguous() and tuple(a16.shape) == (M, K)
@@ -120,7 +120,7 @@ def patch_embed(images: torch.Tensor, conv_w: torch.Tensor, pos: torch.Tensor, x
     width, _, ps, _ = conv_w.shape
     assert ch == 3
     P = (R // ps) ** 2
-    g = GemmArgs()
+    g = _lib.new_gemm_args()
     g.A, g.B, g.C = _p(images), _p(conv_w), _p(x)
     g.M, g.N, g.K = B * P, width, 3 * ps * ps
     g.lda, g.ldb, g.ldc = 0, 3 * ps * ps, width

@@ -21,6 +21,15 @@
 
 #include <vector>
 
+// Timing-only ablations of the K loop (skip the prefetch / the LDS stores / the barrier / the fragment reads / the epilogue:
+// WRONG results) exist only in a diagnostic build: `HIPCC_EXTRA=-DCLIPFS_ABLATION_BUILD python build.py --force`, then
+// CLIPFS_GEMM_ABLATE=<bits> (scripts/ablate_gemm.py).  The shipped library compiles them out.
+#ifdef CLIPFS_ABLATION_BUILD
+#define CLIPFS_ABLATE(mask, bit) ((mask) & (bit))
+#else
+#define CLIPFS_ABLATE(mask, bit) 0
+#endif
+
 namespace clipfs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -245,11 +254,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   store_lds(0);
   __syncthreads();
   for (int kt = 0; kt + 1 < nk; ++kt) {
-    if (!(p.ablate & 1)) load_global(kt0 + kt + 1);  // global -> registers, one K-step ahead
+    if (!CLIPFS_ABLATE(p.ablate, 1)) load_global(kt0 + kt + 1);  // global -> registers, one K-step ahead
     __builtin_amdgcn_sched_barrier(0);         // keep the loads ABOVE the MFMAs (hipcc sinks them to the ds_write otherwise)
     compute(smem + (kt & 1) * STAGE_FLOATS);   // 32 MFMAs per wave hide the load latency
-    if (!(p.ablate & 2)) store_lds((kt + 1) & 1);  // registers -> the other LDS stage
-    if (!(p.ablate & 4)) __syncthreads();
+    if (!CLIPFS_ABLATE(p.ablate, 2)) store_lds((kt + 1) & 1);  // registers -> the other LDS stage
+    if (!CLIPFS_ABLATE(p.ablate, 4)) __syncthreads();
   }
   compute(smem + ((nk - 1) & 1) * STAGE_FLOATS);
   }
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  
   const int abl = p.ablate;
   auto issue_next = [&]() __attribute__((always_inline)) {  // LDS-DMA of the next K-step of the list (no-op at its end)
     if (!lhave) return;
-    if (!(abl & 1) || issued < 2) glds_stage(lkt, lstage);
+    if (!CLIPFS_ABLATE(abl, 1) || issued < 2) glds_stage(lkt, lstage);
     lstage = lstage == NSTAGE - 1 ? 0 : lstage + 1;
     ++issued;
     if (++lkt == lseg.ke) {
@@ -483,24 +492,24 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  
       __builtin_amdgcn_sched_barrier(0);
       mfma_part(f0, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(abl & 8)) read_frag(f1, st, 1);
+      if (!CLIPFS_ABLATE(abl, 8)) read_frag(f1, st, 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma_part(f0, 1, 4);
       mfma_part(f1, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(abl & 8)) read_frag(f0, st, 2);
+      if (!CLIPFS_ABLATE(abl, 8)) read_frag(f0, st, 2);
       __builtin_amdgcn_sched_barrier(0);
       mfma_part(f1, 1, 4);
       mfma_part(f0, 0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!(abl & 8)) read_frag(f1, st, 3);
+      if (!CLIPFS_ABLATE(abl, 8)) read_frag(f1, st, 3);
       __builtin_amdgcn_sched_barrier(0);
       mfma_part(f0, 1, 4);
       mfma_part(f1, 0, 1);  // needs the last fragments: this wave is done reading the stage
       __builtin_amdgcn_sched_barrier(0);
       ++done;
-      if (abl & 4) {
-        if (!(abl & 8)) read_frag(f0, smem + nstage * STAGE_FLOATS, 0);
+      if (CLIPFS_ABLATE(abl, 4)) {
+        if (!CLIPFS_ABLATE(abl, 8)) read_frag(f0, smem + nstage * STAGE_FLOATS, 0);
       } else if (issued > done) {  // another K-step follows (this tile's or the next one's): barrier INSIDE the last group
         if (NSTAGE >= 3 && issued >= done + NSTAGE - 1)
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (A_CHUNKS + B_CHUNKS)) : "memory");  // all but the youngest K-steps' LDS-DMA
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  
     const int mw = m0 + wm * (BM / WM), nw = n0 + wn * (BN / WN);
     const bool full_tile = m0 + BM <= M && n0 + BN <= N;
 
-    if (abl & 16) {
+    if (CLIPFS_ABLATE(abl, 16)) {
       if (acc[0][0][0] == 123.456f) g.C[0] = 1.f;  // keep the accumulators alive
     } else if (cur.kb == 0 && cur.ke == nk) {
       finish_tiles<TM, TN>(g, p.patches, acc, mw, nw, full_tile, lane);
@@ -860,6 +869,9 @@ extern "C" int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream) {
 static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   CLIPFS_REQUIRE(args != nullptr, "gemm: null args");
   const clipfs_gemm_args& a = *args;
+  CLIPFS_REQUIRE(a.struct_size == sizeof(clipfs_gemm_args),
+                 "gemm: args built against another clipfs.h (struct_size %zu, library has %zu)", a.struct_size,
+                 sizeof(clipfs_gemm_args));
   CLIPFS_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad dims %d %d %d", a.M, a.N, a.K);
   if (a.A_f16) {  // f16 x f16 kernel
     CLIPFS_REQUIRE(a.B_planes && a.b_format == 2, "gemm: A_f16 needs the f16 copy of B (b_format 2)");
@@ -884,8 +896,12 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   GemmParams p;
   p.a = a;
   p.patches = 0;
+#ifdef CLIPFS_ABLATION_BUILD
   static const int ablate_cfg = getenv("CLIPFS_GEMM_ABLATE") ? atoi(getenv("CLIPFS_GEMM_ABLATE")) : 0;
   p.ablate = ablate_cfg;
+#else
+  p.ablate = 0;
+#endif
   p.grid_g = 0;
   static const int gm_cfg = getenv("CLIPFS_GEMM_GM") ? atoi(getenv("CLIPFS_GEMM_GM")) : 8;  // tuning aid
   p.gm = gm_cfg > 0 ? gm_cfg : 8;

@@ -83,6 +83,9 @@ static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
 
 static int check_tower(const clipfs_tower* t, int batch) {
   CLIPFS_REQUIRE(t && t->blocks, "tower: null descriptor");
+  CLIPFS_REQUIRE(t->struct_size == sizeof(clipfs_tower) && t->block_size == sizeof(clipfs_block),
+                 "tower: descriptor built against another clipfs.h (struct_size %zu / block_size %zu, library has %zu / %zu)",
+                 t->struct_size, t->block_size, sizeof(clipfs_tower), sizeof(clipfs_block));
   CLIPFS_REQUIRE(batch > 0 && t->layers > 0 && t->seq > 0 && t->heads > 0 && t->width == t->heads * 64,
                  "tower: width %d must be heads %d * 64", t->width, t->heads);
   CLIPFS_REQUIRE(t->lora_r >= 0 && t->lora_r <= 16, "tower: lora rank %d unsupported", t->lora_r);
@@ -127,6 +130,7 @@ static int gemm(const TowerCtx& cx, const float* A, const float* B, const void* 
                 const float* lb, int r, int nseg, int segw, float lscale, hipStream_t st, int chain = CHAIN_NONE,
                 const void* a16_ready = nullptr, void* c16_only = nullptr) {
   clipfs_gemm_args a = {};
+  a.struct_size = sizeof(a);
   a.B_planes = Bp;
   a.b_format = cx.b_format;
   a.workspace = cx.ws;
@@ -167,17 +171,17 @@ static int gemm(const TowerCtx& cx, const float* A, const float* B, const void* 
 using namespace clipfs;
 
 extern "C" size_t clipfs_tower_saved_floats(const clipfs_tower* t, int batch) {
-  if (!t || batch <= 0) return 0;
+  if (!t || batch <= 0 || t->struct_size != sizeof(clipfs_tower)) return 0;
   return saved_layout(t, (size_t)batch * t->seq).total * (size_t)t->layers;
 }
 
 extern "C" size_t clipfs_tower_scratch_floats(const clipfs_tower* t, int batch) {
-  if (!t || batch <= 0) return 0;
+  if (!t || batch <= 0 || t->struct_size != sizeof(clipfs_tower)) return 0;
   return scratch_layout(t, (size_t)batch * t->seq).total;
 }
 
 extern "C" size_t clipfs_tower_counter_ints(const clipfs_tower* t, int batch) {
-  if (!t || batch <= 0) return 0;
+  if (!t || batch <= 0 || t->struct_size != sizeof(clipfs_tower)) return 0;
   return scratch_layout(t, (size_t)batch * t->seq).counter_ints;
 }
 

@@ -132,13 +132,25 @@ class _NativeBpe:
             pass
 
 
+_WARNED_NATIVE = False
+
+
 class SimpleTokenizer:
     """``native=True`` (default): the merge loop runs in the library's C++ BPE core; ``native=False`` keeps the pure
     Python loop below (the cross-check of tests/test_tokenizer.py).  Both produce the same ids."""
 
     def __init__(self, bpe_path: str = None, native: bool = True):
         merges = _read_merges(bpe_path or default_bpe())
-        self._native = _NativeBpe(merges) if native else None
+        self._native = None
+        if native:  # a preference, not a requirement: host-side tokenisation must work on a box without the built library
+            try:
+                self._native = _NativeBpe(merges)
+            except (OSError, RuntimeError) as e:  # ClipfsError is a RuntimeError
+                global _WARNED_NATIVE
+                if not _WARNED_NATIVE:
+                    import warnings
+                    warnings.warn(f"native BPE core unavailable ({e}); using the Python merge loop (same ids)")
+                    _WARNED_NATIVE = True
         self._id_cache: Dict[str, List[int]] = {}
         b2u = bytes_to_unicode()
         self.byte_encoder = b2u

@@ -95,6 +95,9 @@ def mark_only_lora_as_trainable(model, bias: str = 'none') -> None:
                 m.bias.requires_grad_(True)
     else:
         raise NotImplementedError
+    import warnings
+    warnings.warn(f"mark_only_lora_as_trainable(bias={bias!r}): the flags are set as the reference sets them, but the fused "
+                  "backward (LoRATrainer) produces adapter / prompt gradients only -- these biases will NOT be trained")
 
 
 def lora_state_dict(model, bias: str = 'none'):
@@ -279,6 +282,13 @@ class PlainMultiheadAttentionLoRA(nn.Module, LoRALayer):
         if need_weights:
             raise NotImplementedError("attention weights are never materialised (need_weights=False only)")
         L, N, d = query.shape
+        if attn_mask is not None:
+            # the kernels implement exactly one mask: the causal -inf-above-the-diagonal mask of the text tower
+            # (jclip/model.py:189-193); anything else would be applied silently wrong
+            am = torch.as_tensor(attn_mask)
+            causal = torch.full((L, L), float("-inf"), device=am.device, dtype=torch.float32).triu_(1)
+            if tuple(am.shape) != (L, L) or not torch.equal(am.float(), causal):
+                raise NotImplementedError("attn_mask must be the causal mask (-inf above the diagonal, 0 elsewhere)")
         r = self.r
         x = query.permute(1, 0, 2).reshape(N * L, d).contiguous().float()
         p = float(self.dropout_rate) if self.training else 0.0
@@ -613,6 +623,11 @@ class LoRATrainer:
         classes = captions.shape[0] // t
         d = m.embed_dim
         c_lo, c_hi = D.block_bounds(classes, self.rank, self.world) if self.shard_text else (0, classes)
+        if self.shard_text and eng.trim_text and m.training and eng.txt.lora_dropout_rate() > 0:
+            # dropout masks are indexed by token row = caption * seq + position; trimming makes `seq` the local shard's
+            # last EOT, so ranks would index different (and overlapping) rows than the one-process run
+            raise ValueError("trim_text cannot be combined with a class-sharded text tower and LoRA dropout > 0: the "
+                             "Philox rows would depend on each rank's trimmed length (use trim_text=False or shard_text=False)")
         xb = self._exchange_buffers(classes, d) if self.shard_text else None
         # The two towers are independent until the logits: the text tower runs on a side HIP stream so that
         # its kernels fill the CUs the image tower's launches leave idle (small per-rank batches) and vice versa.
@@ -632,6 +647,7 @@ class LoRATrainer:
             full = self._timed("all_gather", lambda: D.allgather_blocks(xb["send"], xb["full"], self.pg))
             txt = full[:classes]
         logits = ops.gemm_nt(img_n, txt, alpha=self.logit_scale)
+        self.last_features = (img_n, txt)  # unit image features of this rank's shard, unit class features [C, d] (tests)
         loss_sum, dl, correct = ops.cross_entropy(logits, target, True, grad_scale=B / gb)
         d_img_n = ops.matmul_small(dl, txt, B, d, classes, classes, 1, d, 1, self.logit_scale)
         d_txt = ops.matmul_small(dl, img_n, classes, d, B, 1, classes, d, 1, self.logit_scale,

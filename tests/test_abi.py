@@ -35,7 +35,7 @@ def test_signature_table_matches_header():
     from clipfs import _lib
     assert sorted(_lib.SIGNATURES) == _header_functions()
     lib = _lib.load()
-    assert lib.clipfs_abi_version() == 1
+    assert lib.clipfs_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_argument_errors_do_not_touch_the_gpu():
@@ -48,8 +48,26 @@ def test_argument_errors_do_not_touch_the_gpu():
     rc = lib.clipfs_attention_fwd(None, None, None, 1, 5000, 2, 0, None)
     assert rc == 1 and b"seq" in lib.clipfs_last_error()
     assert lib.clipfs_gemm_nt(None, None) == 1
+    # ABI v2: a descriptor built against another header (wrong struct_size) is rejected before anything is read from it
+    g = _lib.GemmArgs()
+    g.M = g.N = g.K = 32
+    assert lib.clipfs_gemm_nt(ctypes.byref(g), None) == 1 and b"struct_size" in lib.clipfs_last_error()
+    t = _lib.Tower()
+    blocks = (_lib.Block * 1)()
+    t.blocks = ctypes.cast(blocks, ctypes.POINTER(_lib.Block))
+    t.width, t.heads, t.layers, t.seq = 64, 1, 1, 8
+    assert lib.clipfs_tower_fwd(ctypes.byref(t), None, 1, None, None, None) == 1
+    assert b"struct_size" in lib.clipfs_last_error()
+    assert lib.clipfs_tower_scratch_floats(ctypes.byref(t), 1) == 0
+    assert lib.clipfs_tower_scratch_floats(ctypes.byref(_fill(_lib.new_tower(), t)), 1) > 0
     with pytest.raises(_lib.ClipfsError):
         _lib.check(rc, "attention_fwd")
+
+
+def _fill(dst, src):
+    for name in ("blocks", "width", "heads", "layers", "seq"):
+        setattr(dst, name, getattr(src, name))
+    return dst
 
 
 def test_product_does_not_import_the_oracle():

@@ -20,12 +20,11 @@ def _free_port():
     return p
 
 
-def _setup():
+def _setup(B=6, Cn=7):
     from clipfs import synth
     cfg = synth.TINY
     sd = {k: v.double() for k, v in synth.synth_state_dict(cfg, seed=21, perturb=True).items()}
     lw = synth.synth_lora(cfg, 4, seed=22)
-    B, Cn = 6, 7
     img = synth.synth_images(B, cfg.image_resolution, seed=23).double()
     cap = synth.synth_captions(Cn, cfg.context_length, cfg.vocab_size, seed=24, max_len=9)
     tgt = synth.synth_labels(B, Cn, seed=25)
@@ -41,14 +40,14 @@ def _adapters(cfg, lw):
     return tl, vl, flat
 
 
-def _rank_main(rank, world, port, shard_text, out_dir):
+def _rank_main(rank, world, port, shard_text, out_dir, B=6, Cn=7):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     from clipfs import dist as D
     from oracle import clip_oracle as O
-    cfg, sd, lw, img, cap, tgt = _setup()
+    cfg, sd, lw, img, cap, tgt = _setup(B, Cn)
     tl, vl, flat = _adapters(cfg, lw)
     ctx = sd["token_embedding.weight"][[9, 10, 11, 12]].clone().requires_grad_()
     B, Cn = img.shape[0], cap.shape[0]
@@ -87,6 +86,40 @@ def _rank_main(rank, world, port, shard_text, out_dir):
     if rank == 0:
         np.savez(os.path.join(out_dir, f"dp_{int(shard_text)}.npz"), grads=grads.numpy(), loss=total.numpy())
     dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_at_cfg3_counts(tmp_path):
+    """cfg-3's partition on 8 ranks (gloo, CPU, oracle compute on the TINY model): B = 256 -> 32 images per rank,
+    C = 403 classes -> blocks of S = 51 with a short last block (46 rows), one all_gather + one reduce_scatter + one
+    all-reduce; the summed gradient must equal the single-process gradient of the whole batch."""
+    from clipfs import dist as D
+    from oracle import clip_oracle as O
+    B, Cn, world = 256, 403, 8
+    assert D.block_rows(Cn, world) == 51 and D.block_bounds(Cn, 7, world) == (357, 403)
+    assert [D.shard_bounds(B, r, world) for r in (0, 7)] == [(0, 32), (224, 256)]
+    cfg, sd, lw, img, cap, tgt = _setup(B, Cn)
+    tl, vl, flat = _adapters(cfg, lw)
+    ctx = sd["token_embedding.weight"][[9, 10, 11, 12]].clone().requires_grad_()
+    loss, _ = O.train_step_loss(sd, img, cap, tgt, tl, vl, 0.5, ctx=ctx)
+    loss.backward()
+    want = torch.cat([t.grad.reshape(-1) for t in flat] + [ctx.grad.reshape(-1)]).numpy()
+    mp.spawn(_rank_main, args=(world, _free_port(), True, str(tmp_path), B, Cn), nprocs=world, join=True)
+    z = np.load(os.path.join(str(tmp_path), "dp_1.npz"))
+    assert abs(float(z["loss"][0]) - loss.item()) < 1e-11
+    assert np.allclose(z["grads"], want, atol=1e-11, rtol=1e-8)
+    assert np.abs(want).max() > 1e-5
+
+
+def test_exchange_helpers_reject_wrong_shapes():
+    from clipfs import dist as D
+    blk = torch.zeros(3, 4)
+    with pytest.raises(ValueError):
+        D.allgather_blocks(blk, torch.zeros(4, 4))
+    with pytest.raises(ValueError):
+        D.allgather_blocks(torch.zeros(4, 6)[:, :4], torch.zeros(4, 4))
+    with pytest.raises(ValueError):
+        D.reduce_scatter_blocks(torch.zeros(3, 4), torch.zeros(2, 4))
+    assert D.allgather_blocks(blk).shape == (3, 4) and D.reduce_scatter_blocks(blk).shape == (3, 4)
 
 
 @pytest.mark.parametrize("shard_text", [True, False])

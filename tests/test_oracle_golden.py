@@ -144,3 +144,30 @@ def test_full_depth_fixture_eval_logits(golden_dir):
     assert np.array_equal(O.jt_topk(ev.float(), 5).numpy(), z["eval_top5"])
     # 12 text + 12 vision blocks x (A_qkv [3r, d] + B_qkv [3d, r]) at r = 4, plus the 4 x 512 prompt tokens
     assert z["flat_grad"].size == 12 * 2 * 3 * 4 * 512 + 12 * 2 * 3 * 4 * 768 + 4 * 512
+
+
+def test_vitl14_full_depth_fixture(golden_dir):
+    """vitl14_full_step.npz (cfg-5 at full depth): one image and two captions of its dropout-free forward are recomputed
+    here in fp64 (the train step with the 2.95 M-float gradient is regenerated by make_golden.py only); the gradient
+    bookkeeping (sizes, stride sample, per-tensor norms) must be self-consistent."""
+    z = np.load(os.path.join(golden_dir, "vitl14_full_step.npz"))
+    cfg = synth.VIT_L14
+    sd = {k: v.double() for k, v in synth.synth_state_dict(cfg, seed=1234).items()}
+    lw = synth.synth_lora(cfg, 16, seed=5, vision_blocks=range(21))
+    tl, vl = O.split_lora_checkpoint(lw, "both", "all", "ViT-L/14")
+    assert sorted(vl) == list(range(21))  # the reference adapts vision blocks 0-20 only (lora_train_vlp.py:62)
+    img = synth.synth_images(4, 224, seed=0)[:1].double()
+    cap = synth.synth_captions(8, 77, cfg.vocab_size, seed=1)[:2]
+    ctx = sd["token_embedding.weight"][[320, 1125, 539, 320]]
+    s = O.lora_scaling(1, 16)
+    assert s == 0.25
+    with torch.no_grad():
+        fi = O.l2_normalize(O.encode_image(sd, img, vl, s))
+        ft = O.l2_normalize(O.encode_text(sd, cap, tl, s, embeds=O.build_prompts(ctx, sd["token_embedding.weight"], cap)))
+    assert np.allclose(fi.numpy(), z["img_feat"][:1], atol=1e-10)
+    assert np.allclose(ft.numpy(), z["txt_feat"][:2], atol=1e-10)
+    assert np.allclose((100.0 * fi @ ft.t()).numpy(), z["eval_logits"][:1, :2], atol=1e-8)
+    sizes = z["tensor_sizes"]
+    assert len(sizes) == 2 * (12 + 21) + 1 and int(sizes.sum()) == int(z["grad_numel"]) == 12 * 2 * 48 * 768 + 21 * 2 * 48 * 1024 + 4 * 768
+    assert z["flat_grad_strided"].size == -(-int(z["grad_numel"]) // int(z["grad_stride"]))
+    assert abs(float(np.sqrt((z["tensor_norms"] ** 2).sum())) - float(z["grad_l2"])) < 1e-9 * float(z["grad_l2"])
