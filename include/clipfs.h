@@ -91,15 +91,15 @@ typedef struct clipfs_gemm_args {
   const void* B_planes;    /* optional 16-bit copy of B (a_mode 0, K % 32 == 0, ldb == K); NULL = exact fp32 */
   int b_format;            /* 1: bf16 hi/lo planes (clipfs_split_bf16) -> split-bf16 x3 kernel;
                               2: one f16 plane (clipfs_convert_f16) -> f16 MFMA kernel (cfg-5's fp16 path) */
-  float* workspace;        /* optional split-K scratch (NULL: never split); see clipfs_gemm_workspace_floats */
+  float* workspace;        /* optional split-K / stream-K slab scratch, 16-byte aligned (NULL: never split) */
   size_t workspace_floats;
   const void* A_f16;       /* optional f16 copy of A [M,K] (ld = lda): with b_format 2 selects the f16 x f16 kernel
                               (operands stream HBM -> LDS -> MFMA untouched); A may then be NULL */
   void* C_f16;             /* f16 x f16 kernel only: also (or, with C == NULL, only) write the result as f16, ld = ldc */
   int aux_f16;             /* f16 x f16 kernel only: aux_out / aux_in hold f16 values (fp16 storage of the saved
                               pre-activation), ld = ldc */
-  int* counters;           /* optional stream-K arrival counters: >= clipfs_gemm_counter_ints(M,N,K) ints, ZERO on entry
-                              (the kernel leaves them zero); with `workspace` enables the stream-K schedule */
+  int* counters;           /* optional arrival counters (split-K, stream-K): >= clipfs_gemm_counter_ints(M,N,K) ints, ZERO on
+                              entry (the kernel leaves them zero); with `workspace` enables those schedules */
   size_t counters_ints;
 } clipfs_gemm_args;
 /* Ordering: everything the call does is ordered on `stream` (work queued on it before the call happens-before, work
@@ -107,10 +107,12 @@ typedef struct clipfs_gemm_args {
  * stream, forked from and joined back into `stream` with events inside the call (one side stream per caller stream
  * and host thread, created on first use). */
 int clipfs_gemm_nt(const clipfs_gemm_args* args, void* stream);
-/* Products with few output tiles (small per-rank batches) are cut along K into `clipfs_gemm_splits` slices
- * whose raw partial sums go to `workspace` and are combined, in slice order, by a second kernel that applies
- * the epilogue -- deterministic, no float atomics.  workspace_floats >= clipfs_gemm_workspace_floats(M,N,K)
- * enables it; 0 is returned for shapes that are never split. */
+/* Products with few output tiles (small per-rank batches, the one-row-per-sequence products of the last block) are
+ * cut along K into `clipfs_gemm_splits` slices.  Every slice writes its raw partial tile to `workspace` and the slice
+ * that arrives LAST at the tile's arrival counter (`counters`) adds the slices in slice order and applies the epilogue,
+ * inside the same launch -- deterministic, no float atomics, no second kernel.  Enabled when workspace_floats >=
+ * clipfs_gemm_workspace_floats(M,N,K) AND counters_ints >= clipfs_gemm_counter_ints(M,N,K) (both 0 for shapes that
+ * are never split); `counters` must be zero on entry and is left zero. */
 /* planes[0..n) = bf16(src), planes[n..2n) = bf16(src - hi): the frozen-weight half of the opt-in split-bf16
  * ("bf16 x 3") GEMM: a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate.
  * `planes` holds 2*n bf16 values (4*n bytes); n % 8 == 0. */

@@ -46,18 +46,22 @@ def source_stamps():
             _stamp([os.path.join(CSRC, "gemm.hip"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "common.h")]))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+def build(force: bool = False, verbose: bool = True, tag: str = "") -> str:
+    """``tag``: an EXPERIMENT build (extra flags from $HIPCC_EXTRA) kept apart from the product library: objects under
+    csrc/build/<tag>/, output clipfs/libclipfs_hip_<tag>.so, loaded only when CLIPFS_LIB_TAG=<tag> is set."""
+    bdir = os.path.join(CSRC, "build", tag) if tag else os.path.join(CSRC, "build")
+    out = OUT.replace(".so", f"_{tag}.so") if tag else OUT
+    os.makedirs(bdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "clipfs.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     lib_stamp, gemm_stamp = source_stamps()
-    stamp_file = os.path.join(CSRC, "build", "stamp.txt")
+    stamp_file = os.path.join(bdir, "stamp.txt")
     stamp_now = lib_stamp + " " + gemm_stamp
     stamp_old = open(stamp_file).read().strip() if os.path.exists(stamp_file) else ""
     objs, jobs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, "build", s.replace(".hip", ".o"))
+        obj = os.path.join(bdir, s.replace(".hip", ".o"))
         objs.append(obj)
         extra = []
         if s == "common.hip":  # carries the source stamps: rebuilt whenever any source changed
@@ -76,12 +80,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _newer(OUT, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs])
+    if force or jobs or _newer(out, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
     with open(stamp_file, "w") as f:
         f.write(stamp_now + "\n")
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else ""
+    print(build(force="--force" in sys.argv, tag=tag))

@@ -12,7 +12,10 @@ import os
 ABI_VERSION = 2  # CLIPFS_ABI_VERSION of include/clipfs.h this table was written against
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclipfs_hip.so")
+# CLIPFS_LIB_TAG=<tag>: an experiment build made with `build.py --tag <tag>` (A/B timing of kernel variants in one
+# gpurun call; bench.py lists it among the active overrides).  Unset = the product library.
+_TAG = os.environ.get("CLIPFS_LIB_TAG", "")
+LIB_PATH = os.path.join(_HERE, f"libclipfs_hip_{_TAG}.so" if _TAG else "libclipfs_hip.so")
 
 c_f32p = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 c_stream = C.c_void_p

@@ -45,7 +45,8 @@ def _gemm_counters(device, n: int) -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, *, bias=None, residual=None,
             act: int = 0, aux_out=None, aux_in=None, alpha: float = 1.0, lora_t=None, lora_b=None,
             lora_seg_width: int = 0, lora_scale: float = 0.0, split_k: bool = True, b_planes=None,
-            a16: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None, only16: bool = False) -> torch.Tensor:
+            a16: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None, only16: bool = False,
+            aux_f16: bool = False) -> torch.Tensor:
     """out = epi(alpha * a @ b.T); a [M,K], b [N,K].  ``a16`` (f16 [M,K]) with f16 ``b_planes`` selects the
     f16 x f16 kernel (``a`` may then be None); ``out16`` (f16 [M,N]) receives an f16 copy of the result."""
     if a is not None:
@@ -73,6 +74,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None
     g.act = act
     g.aux_out = _p(aux_out)
     g.aux_in = _p(aux_in)
+    g.aux_f16 = int(aux_f16)  # f16 x f16 kernel: aux_out / aux_in are f16 tensors (fp16 storage of the pre-activation)
     if lora_t is not None:
         r = lora_b.shape[1]
         g.lora_t, g.lora_b = _p(_f32(lora_t)), _p(_f32(lora_b))

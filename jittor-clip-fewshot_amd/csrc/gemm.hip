@@ -30,6 +30,33 @@
 #define CLIPFS_ABLATE(mask, bit) 0
 #endif
 
+#ifdef CLIPFS_STAMPS
+// Diagnostic build only (HIPCC_EXTRA=-DCLIPFS_STAMPS, build.py --tag stamps): s_memtime at four points of every
+// workgroup of gemm_nt_kernel + the hardware ids of the CU it ran on, written to a buffer nothing else reads
+// (scripts/gemm_stamps.py).
+__device__ unsigned long long clipfs_gemm_stamps[16384 * 6];
+#define CLIPFS_STAMP(i)                                                                                     \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                           \
+      clipfs_gemm_stamps[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memtime();                              \
+      if ((i) == 1) clipfs_gemm_stamps[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_memrealtime();              \
+      if ((i) == 2) clipfs_gemm_stamps[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();              \
+      if (0) {                                                                                       \
+        unsigned hw, xcc;                                                                                   \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                  \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                \
+        clipfs_gemm_stamps[blockIdx.x * 6 + 4] = hw;                                                        \
+        clipfs_gemm_stamps[blockIdx.x * 6 + 5] = xcc;                                                       \
+      }                                                                                                     \
+    }                                                                                                       \
+  } while (0)
+extern "C" int clipfs_debug_read_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clipfs_gemm_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define CLIPFS_STAMP(i) do {} while (0)
+#endif
+
 namespace clipfs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,6 +85,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   constexpr int STAGE_FLOATS = (BM + BN) * BK;
 
   const clipfs_gemm_args& g = p.a;
+  CLIPFS_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -242,6 +270,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   if (AMODE == 3) {
     glds_stage(kt0, 0);
     __syncthreads();  // emits vmcnt(0) for the LDS-DMA in flight, then the barrier
+    CLIPFS_STAMP(1);
     for (int kt = 0; kt + 1 < nk; ++kt) {
       glds_stage(kt0 + kt + 1, (kt + 1) & 1);  // the other stage was last read before the previous barrier
       compute(smem + (kt & 1) * STAGE_FLOATS);
@@ -263,24 +292,70 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
   compute(smem + ((nk - 1) & 1) * STAGE_FLOATS);
   }
 
+  CLIPFS_STAMP(2);
   // ---- LoRA up-projection on the matrix cores + epilogue (gemm_common.h) ------------------------------------
   if (p.splits > 1) {
-    // raw partial sums of this K slice; gemm_splitk_combine_kernel adds the slices in order and applies the epilogue
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / WN) + j * 32 + fr;
-      if (n >= N) continue;
+    // Split-K without a combine launch: every K slice publishes its raw accumulators as a slab (register order: one
+    // 16-byte store per lane, fully coalesced) WRITE-THROUGH (sc1), takes a ticket on the tile's arrival counter, and
+    // the slice that arrives LAST adds the slabs in slice order -- bitwise reproducible whatever the arrival order --
+    // and runs the same LoRA + epilogue code as an unsplit tile.  Nobody waits, so no residency assumption; every slab
+    // load is an sc1 load (bypasses this CU's L1, which no other CU's store refreshes): no release / acquire fence
+    // (same hand-off as the stream-K kernel below; MI355X_MICROARCH.md "Valid forms").  The counter is left zero.
+    constexpr int SLAB = BM * BN;
+    const int S = p.splits;
+    {
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(p.part + ((size_t)tile * S + split) * SLAB, 0, SLAB * 4, 0x00020000);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          if (m < M) p.part[((size_t)split * M + m) * N + n] = acc[i][j][r];
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const f32x4 val = f32x4{acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, val), rs,
+                                                   (((i * TN + j) * 4 + v) * 256 + tid) * 16, 0, /*sc1*/ 16);
+          }
+    }
+    int* flag = reinterpret_cast<int*>(smem + 2 * STAGE_FLOATS);  // one word behind the two stages (the host adds it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores ...
+    __syncthreads();                                    // ... before ONE lane signals (also: everybody is done with the stages)
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(p.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == S - 1;
+      if (last) __hip_atomic_store(p.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (S > 2) {  // (s0 + s1) + s2 + ...: every slab from memory, the own one included (it was stored write-through)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    for (int c = 0; c < S; ++c) {
+      if (S == 2 && c == split) continue;  // two slices: a + b == b + a, the own slab stays in registers
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(p.part + ((size_t)tile * S + c) * SLAB, 0, SLAB * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x4 u[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            u[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 rs, (((i * TN + j) * 4 + v) * 256 + tid) * 16, 0, /*sc1*/ 16));
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * v + e] += u[v][e];
         }
     }
-    return;
   }
   finish_tiles<TM, TN>(g, p.patches, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), m0 + BM <= M && n0 + BN <= N, lane);
+  CLIPFS_STAMP(3);
 }
 
 // ---- stream-K ------------------------------------------------------------------------------------------------
@@ -301,8 +376,11 @@ struct SkSeg {
   int tile, kb, ke;
 };
 
+#ifndef CLIPFS_SK_WAVES
+#define CLIPFS_SK_WAVES 2  // waves per SIMD the stream-K kernel is compiled for (2: <= 256 registers)
+#endif
 template <int BM, int BN, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  // 2 waves per SIMD: <= 256 registers
+__global__ __launch_bounds__(256, CLIPFS_SK_WAVES) void gemm_sk_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WM = BM >= 64 ? 2 : 1;
   constexpr int WN = 4 / WM;
@@ -430,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  
     tile_origin(lseg.tile, lm0, ln0);
     set_sources(lm0, ln0);
   }
-  const int abl = p.ablate;
+  [[maybe_unused]] const int abl = p.ablate;
   auto issue_next = [&]() __attribute__((always_inline)) {  // LDS-DMA of the next K-step of the list (no-op at its end)
     if (!lhave) return;
     if (!CLIPFS_ABLATE(abl, 1) || issued < 2) glds_stage(lkt, lstage);
@@ -601,17 +679,6 @@ __global__ __launch_bounds__(256, 2) void gemm_sk_kernel(const GemmParams p) {  
   }
 }
 
-// split-K combine: C = epilogue( sum_s part[s] ), slabs added in index order (bitwise reproducible)
-__global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(const GemmParams p) {
-  const clipfs_gemm_args& g = p.a;
-  const size_t total = (size_t)g.M * g.N;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    float v = 0.f;
-    for (int s = 0; s < p.splits; ++s) v += p.part[(size_t)s * total + i];
-    epilogue_store(g, p.patches, (int)(i / g.N), (int)(i % g.N), v);
-  }
-}
-
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream around every
 // GEMM while enabled.  Off by default; never on in the timed region.
 struct TimedLaunch {
@@ -630,7 +697,7 @@ static int launch(const GemmParams& p, hipStream_t stream) {
   // (the MFMA pipe is the shared resource either way) and the third of the CU left free lets the other tower's
   // LayerNorm / attention / LoRA kernels run beside the GEMM: +1.3 % on the step, +3.4 % on the 8-GPU per-rank step.
   static const int lds_pad = getenv("CLIPFS_GEMM_LDS_PAD") ? atoi(getenv("CLIPFS_GEMM_LDS_PAD")) : 8;  // KiB
-  const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float) + (size_t)lds_pad * 1024;
+  const size_t lds = 2 * (size_t)(BM + BN) * BK * sizeof(float) + (size_t)lds_pad * 1024 + 64;  // + the split-K flag word
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, AMODE>),
@@ -638,12 +705,6 @@ static int launch(const GemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, AMODE>), dim3(mb * p.n_blocks_n * p.splits), dim3(256), lds, stream, p);
-  CLIPFS_CHECK(launch_status());
-  if (p.splits > 1) {
-    const size_t total = (size_t)p.a.M * p.a.N;
-    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(gemm_splitk_combine_kernel, dim3(blocks), dim3(256), 0, stream, p);
-  }
   return launch_status();
 }
 
@@ -761,16 +822,29 @@ static inline int gemm_bm(int M, int N) {
   return cost32 < cost64 ? 32 : 64;
 }
 
-// Split-K factor for a [M,N,K] product: only when even the 32 x 128 tiling leaves the 256 CUs short of work
-// (strong-scaling per-rank batches) and K is long enough to cut; the slab combine costs one extra pass over
-// S * M * N floats, so it is kept to 2-3 slices.
+// Split-K factor for a [M,N,K] product: only when even the 32 x 128 tiling leaves the 512 resident workgroup slots
+// short of work (strong-scaling per-rank batches, the one-row-per-sequence products of the last block) and K is long
+// enough to cut.  The slices of a tile are combined by the last one to arrive inside the same launch (no second
+// kernel), so the factor aims at ~one unit per slot, with at least 4 K-steps per unit.
 extern "C" int clipfs_gemm_splits(int M, int N, int K) {
-  const long tiles = (long)((M + gemm_bm(M, N) - 1) / gemm_bm(M, N)) * ((N + 127) / 128);
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  static const int force = getenv("CLIPFS_GEMM_SPLITS") ? atoi(getenv("CLIPFS_GEMM_SPLITS")) : 0;  // tuning aid
+  if (force > 0) return (K + BK - 1) / BK >= 2 * force ? force : 1;
+  const int bm = gemm_bm(M, N);
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + 127) / 128);
   const int nk = (K + BK - 1) / BK;
-  if (tiles >= 384 || nk < 16) return 1;
-  int s = tiles < 200 ? 3 : 2;
-  while (s > 1 && nk / s < 8) --s;
-  return s;
+  if (tiles >= 384 || nk < 8) return 1;
+  long s = (448 + tiles - 1) / tiles;
+  if (s > nk / 4) s = nk / 4;
+  if (s > 8) s = 8;
+  return s < 1 ? 1 : (int)s;
+}
+
+// tiles of the tiling gemm_nt_impl picks for a split product (0 when it does not split)
+static inline long splitk_tiles(int M, int N, int K) {
+  if (clipfs_gemm_splits(M, N, K) <= 1) return 0;
+  const int bm = gemm_bm(M, N);
+  return (long)((M + bm - 1) / bm) * ((N + 127) / 128);
 }
 
 static inline bool sk_enabled() {
@@ -789,7 +863,8 @@ static inline void sk_geometry(int M, int N, int K, long* tiles, size_t* slab_fl
 extern "C" size_t clipfs_gemm_workspace_floats(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int s = clipfs_gemm_splits(M, N, K);
-  size_t need = s > 1 ? (size_t)s * M * N : 0;
+  // one slab of a whole tile (BM x 128 floats) per K slice and tile
+  size_t need = s > 1 ? (size_t)s * (size_t)splitk_tiles(M, N, K) * gemm_bm(M, N) * 128 : 0;
   if (sk_enabled() && (K % BK) == 0) {  // stream-K: a head and a tail slab per run
     long tiles;
     size_t sk;
@@ -800,11 +875,15 @@ extern "C" size_t clipfs_gemm_workspace_floats(int M, int N, int K) {
 }
 
 extern "C" size_t clipfs_gemm_counter_ints(int M, int N, int K) {
-  if (M <= 0 || N <= 0 || K <= 0 || !sk_enabled() || (K % BK) != 0) return 0;
-  long tiles;
-  size_t slab;
-  sk_geometry(M, N, K, &tiles, &slab);
-  return slab ? (size_t)tiles : 0;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  size_t need = (size_t)splitk_tiles(M, N, K);  // split-K: one arrival counter per tile
+  if (sk_enabled() && (K % BK) == 0) {
+    long tiles;
+    size_t slab;
+    sk_geometry(M, N, K, &tiles, &slab);
+    if (slab && (size_t)tiles > need) need = (size_t)tiles;
+  }
+  return need;
 }
 
 extern "C" int clipfs_gemm_timing(int enable) {
@@ -926,21 +1005,28 @@ static int gemm_nt_impl(const clipfs_gemm_args* args, void* stream) {
   p.n_blocks_n = 0;
   if (a.B_planes && (a.b_format == 1 || a.b_format == 2) && a.a_mode == 0 && (a.K % BK) == 0 && a.ldb == a.K)
     return gemm_bf16x3_dispatch(p, s);
+  p.sk_cnt = nullptr;
   {
+    // split-K needs the slab scratch AND the (caller-zeroed) arrival counters; dense fp32 operands only
     const int want = clipfs_gemm_splits(a.M, a.N, a.K);
-    if (want > 1 && a.workspace && a.workspace_floats >= (size_t)want * a.M * a.N) {
+    if (want > 1 && a.a_mode == 0 && (a.K % BK) == 0 && a.workspace && a.counters && aligned16(a.workspace) &&
+        a.workspace_floats >= clipfs_gemm_workspace_floats(a.M, a.N, a.K) &&
+        a.counters_ints >= (size_t)splitk_tiles(a.M, a.N, a.K)) {
       p.splits = want;
       p.part = a.workspace;
+      p.sk_cnt = a.counters;
     }
   }
   // 64x128 tiles keep the tile count a large multiple of the CU count at the path's shapes
   // (M = 12800: 200 x N/128 tiles), 128x128 is used when there are plenty of tiles anyway.
   static const int tile_cfg = getenv("CLIPFS_GEMM_TILE") ? atoi(getenv("CLIPFS_GEMM_TILE")) : 0;  // tuning aid
   if (tile_cfg == 1 && a.a_mode == 0 && (a.K % BK) == 0) {
+    p.splits = 1;  // the slab geometry is that of the default tiling
     p.n_blocks_n = (a.N + 127) / 128;
     return launch<128, 128, 3>(p, s);
   }
   if (tile_cfg == 2 && a.a_mode == 0 && (a.K % BK) == 0) {
+    p.splits = 1;
     p.n_blocks_n = (a.N + 63) / 64;
     return launch<128, 64, 0>(p, s);
   }

@@ -390,6 +390,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
 // T16: the accumulators are 8 x 4 tiles of v_mfma_f32_16x16x32_f16 (lane: column l & 15, rows 4 (l >> 4) + r); a store
 // instruction then covers four row groups 4 rows apart, which all fall on the same 16 banks of a 1 KiB-pitch image -- the
 // 16-float column blocks are XORed with the row group ((row >> 2) & 3) on both sides.
+// Epilogue of the 256 x 256 kernels through LDS: the accumulators are transposed through the (now idle) ring in two
+// passes of 128 tile rows, then every thread owns 4 consecutive columns of 16 rows of the pass and does row-major
+// 16-byte accesses.
+// Round 3: in-kernel stamps (scripts/gemm_f16_stamps.py) showed the round-2 form of this epilogue taking 37 % (f16-only
+// result) to 66 % (fp32 result + residual) of a K = 1024 tile's lifetime.  Waits, not bandwidth:
+//   * `__syncthreads()` is a workgroup-scope fence + barrier and the fence is `s_waitcnt vmcnt(0)`: the second pass's
+//     staging waited until EVERY global store of the first pass had been acknowledged by the memory system;
+//   * the per-row loads (residual, saved pre-activation) were issued one row at a time behind the previous row's
+//     store, and vmcnt retires in issue order, so each load also waited for that store: 32 store round trips per tile.
+// Now (a) the staging barriers are raw `s_barrier`s behind `s_waitcnt lgkmcnt(0)` (only LDS traffic has to be ordered);
+// (b) a pass is the UPPER or LOWER 64 rows of every wave's 128-row tile (not one wave row), so all eight waves stage,
+// and after pass 0 every wave has freed half of its accumulators: (c) that room holds ALL per-row loads of a pass at
+// once -- pass 0's are issued before its staging, pass 1's right after it, i.e. before any store of the tile, so no
+// wait for a load ever includes a store; (d) the bias (a thread's columns never change) is loaded once.  Same
+// arithmetic, same order per element: bitwise the same results.  Measured (stamps, K = 1024 tiles): 27.5 -> 15.6 k cycles
+// (f16-only result), 97 -> 44 k (fp32 result + residual: 512 KB per tile at 11.6 B/cycle/CU = this CU's share of HBM),
+// 67 -> 31 k (f16 result x saved pre-activation); cfg-5 step 110.4 -> 102.8 ms.  Tried and dropped: starting the first
+// round's workgroups 0-3 delay steps apart so that the CUs' epilogue bursts do not coincide (no change up to 8 k
+// cycles per step: the epilogue is bound per CU, not by a chip-wide burst).
 template <bool T16, class AccT>
 __device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, AccT& acc, float* lds, int m0, int n0, int wm, int wn,
                                                  int tid) {
@@ -397,71 +416,106 @@ __device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, AccT& acc, 
   const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
   const int Mend = p.m_end, N = g.N, ldc = g.ldc;
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();  // the ring (or the previous half) is no longer read
-    if (wm == half) {
-      if constexpr (T16) {
-        const int li = lane & 15, lg = lane >> 4;
+  constexpr int RP = 16;                   // rows per thread and pass
+  const int c4 = tid & 63, rr = tid >> 6;  // this thread: columns n .. n + 3 of staging rows rr + 8 k
+  const int n = n0 + 4 * c4;
+  const bool n_ok = n < N;                 // N % 4 == 0 (host): the 4 columns are inside together
+  const int nc = n_ok ? n : 0;             // clamped column for the (unused) loads of an outside thread
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + nc);
+  const bool has_res = g.residual != nullptr, act2 = g.act == 2;
+  const _Float16* aux16 = reinterpret_cast<const _Float16*>(g.aux_in);
+  // staging row lr (0 .. 127) of pass ps <-> tile row (lr >> 6) * 128 + ps * 64 + (lr & 63)
+  auto tile_row = [&](int ps, int lr) { return (lr >> 6) * 128 + ps * 64 + (lr & 63); };
+
+  // One load buffer per pass: the residual rows (fp32 x 4) OR the saved pre-activation (f16 x 4 in the low two dwords).
+  // The host never sends both, nor an fp32 pre-activation, to this epilogue (launch_f16_pp: register-epilogue kernel).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x4 ld0[RP], ld1[RP];
+  auto issue_loads = [&](int ps, f32x4 (&r)[RP]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              lds[(i * 16 + 4 * lg + r) * 256 + ((wn * 64 + j * 16 + li) ^ (16 * lg))] = acc[i][j][r];
+    for (int k = 0; k < RP; ++k) {
+      const int m = min(m0 + tile_row(ps, rr + 8 * k), Mend - 1);  // clamped: rows past the end are never stored
+      if (has_res) {
+        r[k] = *reinterpret_cast<const f32x4*>(g.residual + (size_t)m * g.ldres + nc);
       } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              lds[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 256 + wn * 64 + j * 32 + fr] = acc[i][j][r];
+        const f32x2 h = *reinterpret_cast<const f32x2*>(aux16 + (size_t)m * ldc + nc);
+        r[k][0] = h[0];
+        r[k][1] = h[1];
       }
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-      const int q = tid + 512 * k;
-      const int row = q >> 6, c4 = q & 63;
-      const int m = m0 + half * 128 + row, n = n0 + 4 * c4;
-      if (m >= Mend || n >= N) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(lds + row * 256 + ((4 * c4) ^ (T16 ? 16 * ((row >> 2) & 3) : 0)));
-      if (g.bias) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
-        v = g.alpha * v + b4;
-      } else {
-        v = g.alpha * v;
+  };
+  auto stage = [&](int ps) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS-only ordering: global stores are NOT drained
+    __builtin_amdgcn_s_barrier();                        // the ring (or the previous pass's image) is no longer read
+    asm volatile("" ::: "memory");
+    if constexpr (T16) {
+      const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            lds[(wm * 64 + i * 16 + 4 * lg + r) * 256 + ((wn * 64 + j * 16 + li) ^ (16 * lg))] = acc[ps * 4 + i][j][r];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            lds[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 256 + wn * 64 + j * 32 + fr] = acc[ps * 2 + i][j][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto finish = [&](int ps, const f32x4 (&r)[RP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < RP; kb += 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = rr + 8 * (kb + j);
+        v[j] = *reinterpret_cast<const f32x4*>(lds + row * 256 + ((4 * c4) ^ (T16 ? 16 * ((row >> 2) & 3) : 0)));
       }
-      const size_t o = (size_t)m * ldc + n;
-      if (g.act == 1) {
-        if (g.aux_out) {
-          if (g.aux_f16)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + tile_row(ps, rr + 8 * (kb + j));
+        const bool ok = n_ok && m < Mend;
+        f32x4 x = g.bias ? g.alpha * v[j] + b4 : g.alpha * v[j];
+        const size_t o = (size_t)m * ldc + n;
+        if (g.act == 1) {
+          if (g.aux_out && ok)
             *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(g.aux_out) + o) =
-                f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-          else
-            *reinterpret_cast<f32x4*>(g.aux_out + o) = v;
+                f16x4{(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = quick_gelu_fast(x[e]);
+        } else if (act2) {
+          const f16x4 u = __builtin_bit_cast(f16x4, f32x2{r[kb + j][0], r[kb + j][1]});
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] *= quick_gelu_grad_fast((float)u[e]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = quick_gelu_fast(v[e]);
-      } else if (g.act == 2) {
-        f32x4 u;
-        if (g.aux_f16) {
-          const f16x4 h = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(g.aux_in) + o);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) u[e] = (float)h[e];
-        } else {
-          u = *reinterpret_cast<const f32x4*>(g.aux_in + o);
+        if (has_res) x += r[kb + j];
+        if (ok) {
+          if (g.C) *reinterpret_cast<f32x4*>(g.C + o) = x;
+          if (p.C16) *reinterpret_cast<f16x4*>(p.C16 + o) = f16x4{(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad_fast(u[e]);
       }
-      if (g.residual) v += *reinterpret_cast<const f32x4*>(g.residual + (size_t)m * g.ldres + n);
-      if (g.C) *reinterpret_cast<f32x4*>(g.C + o) = v;
-      if (p.C16) *reinterpret_cast<f16x4*>(p.C16 + o) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     }
-  }
+  };
+
+  const bool any_loads = has_res || act2;
+  if (any_loads) issue_loads(0, ld0);  // in flight across the staging of pass 0
+  stage(0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (any_loads) issue_loads(1, ld1);  // half of the accumulators are dead now; still ahead of every store
+  __builtin_amdgcn_sched_barrier(0);
+  finish(0, ld0);
+  __builtin_amdgcn_sched_barrier(0);
+  stage(1);
+  finish(1, ld1);
 }
 
 // ---- 256 x 256 "ping-pong" kernel ---------------------------------------------------------------------------------
@@ -634,9 +688,29 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
 //        in (t,2), restaged in (t+1,1); A1 read in (t,3), restaged in (t+1,2).  A read of phase G is complete
 //        (lgkmcnt(0)) before the reader's second barrier of that phase (<= #2G+3); the restage of phase G+2 is issued
 //        after #2G+4.
+#ifdef CLIPFS_STAMPS
+__device__ unsigned long long clipfs_f16_stamps[8192 * 6];
+#define F16_STAMP(i)                                                                                  \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                      \
+      clipfs_f16_stamps[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memtime();                         \
+      if ((i) == 1) clipfs_f16_stamps[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_memrealtime();        \
+      if ((i) == 2) clipfs_f16_stamps[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();        \
+    }                                                                                                 \
+  } while (0)
+}  // namespace clipfs
+extern "C" int clipfs_debug_read_f16_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clipfs::clipfs_f16_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+namespace clipfs {
+#else
+#define F16_STAMP(i) do {} while (0)
+#endif
+
 template <bool T16>
 __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  F16_STAMP(0);
   constexpr int BM = 256, BN = 256;
   constexpr int HPLANE = 128 * 64;   // bytes of one k-plane (32 k) of a half-tile
   constexpr int HT = 2 * HPLANE;     // 16 KiB
@@ -769,6 +843,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
   __builtin_amdgcn_s_barrier();  // #0
   asm volatile("" ::: "memory");
   if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 falls one barrier behind
+  F16_STAMP(1);
 
   int t = 0;
   for (; t + 2 < nk; ++t) {  // steady state: every stage exists, four half-tiles stay in flight
@@ -811,8 +886,10 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
 #undef PH_SYNC_MFMA
   __builtin_amdgcn_sched_barrier(0);  // nothing of the epilogue (LoRA operand loads) is hoisted into the last phases
   if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
+  F16_STAMP(2);
   if constexpr (!T16) f16_lora_step<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
   f16_epilogue_lds<T16>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
+  F16_STAMP(3);
 }
 
 static int launch_f16_pp(F16Params& p, hipStream_t stream) {
@@ -823,7 +900,10 @@ static int launch_f16_pp(F16Params& p, hipStream_t stream) {
     auto al = [](const void* q, size_t n) { return q == nullptr || ((uintptr_t)q & (n - 1)) == 0; };
     p.row_major_epilogue = cfg != 0 && (a.N & 3) == 0 && (a.ldc & 3) == 0 && (!a.residual || (a.ldres & 3) == 0) &&
                            al(a.C, 16) && al(p.C16, 8) && al(a.bias, 16) && al(a.residual, 16) &&
-                           al(a.aux_out, a.aux_f16 ? 8 : 16) && al(a.aux_in, a.aux_f16 ? 8 : 16);
+                           al(a.aux_out, 8) && al(a.aux_in, 8) &&
+                           // the LDS epilogue reads / writes the pre-activation as f16 only and keeps ONE per-row load
+                           // buffer (residual or pre-activation): everything else goes to the register-epilogue kernel
+                           ((!a.aux_out && a.act != 2) || a.aux_f16) && !(a.residual && a.act == 2);
   }
   const int mb = (p.m_end - p.m_begin + 255) / 256;
   const size_t lds = 4 * (size_t)(2 * 256 * 64);

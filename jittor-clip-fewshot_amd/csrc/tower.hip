@@ -66,12 +66,17 @@ static ScratchLayout scratch_layout(const clipfs_tower* t, size_t M) {
   size_t ws = 0, cnt = 0;
   const int shapes[7][2] = {{3 * (int)d, (int)d}, {(int)d, (int)d}, {4 * (int)d, (int)d}, {(int)d, 4 * (int)d},
                             {(int)d, 3 * (int)d}, {4 * (int)d, (int)d}, {(int)d, (int)d}};
-  for (int i = 0; i < 7; ++i) {
-    const size_t w = clipfs_gemm_workspace_floats((int)M, shapes[i][0], shapes[i][1]);
-    const size_t c = clipfs_gemm_counter_ints((int)M, shapes[i][0], shapes[i][1]);
-    ws = w > ws ? w : ws;
-    cnt = c > cnt ? c : cnt;
-  }
+  // ... at the tower's row count and at one row per sequence (the compact last block: clipfs_tower_fwd_rows /
+  // clipfs_tower_bwd_sparse run their products on `batch` rows)
+  const size_t row_counts[2] = {M, M / (size_t)t->seq};
+  for (int k = 0; k < 2; ++k)
+    for (int i = 0; i < 7; ++i) {
+      if (!row_counts[k]) continue;
+      const size_t w = clipfs_gemm_workspace_floats((int)row_counts[k], shapes[i][0], shapes[i][1]);
+      const size_t c = clipfs_gemm_counter_ints((int)row_counts[k], shapes[i][0], shapes[i][1]);
+      ws = w > ws ? w : ws;
+      cnt = c > cnt ? c : cnt;
+    }
   S.counter_ints = cnt;
   S.gemm_ws = o; S.gemm_ws_floats = ws; o += al4(ws);
   // fp16 storage mode (weight_format 2): f16 images of the GEMM operands, M x 4d halves each
