@@ -47,29 +47,34 @@ __device__ __forceinline__ f16x8 load8(const _Float16* p) { return *reinterpret_
 
 // Stage `L` token rows (fp32 or f16, 64 features at `src`, row stride ld) as f16 into a row-major image and/or a transposed
 // image; tokens [L, Lp) are zero-filled so masked lanes multiply finite values.
+// One work item = 4 consecutive tokens x 8 features, loaded ONCE (4 x 16 / 32 bytes) for both images: the row-major
+// image takes 4 ds_write_b128, the transposed one 8 ds_write_b64 (feature row f: the 4 tokens are consecutive halves).
+// Round 2 wrote the transposed image with 32 ds_write_b16 per item and loaded the source once per image; with one
+// workgroup per CU (the images fill the LDS) that staging ran un-overlapped in front of every head's MFMA phase.
 template <typename T>
 __device__ __forceinline__ void stage_head(const T* __restrict__ src, size_t ld, int L, int Lp, _Float16* rowm,
                                            _Float16* tr) {
   const int TP = Lp + 4;
-  if (rowm)  // feature chunk fastest: coalesced global reads, one ds_write_b128 per (token, chunk)
-    for (int idx = threadIdx.x; idx < Lp * 8; idx += (int)blockDim.x) {
-      const int tok = idx >> 3, c = idx & 7;
-      f16x8 h;
+  const int groups = Lp >> 2;  // Lp % 32 == 0
+  for (int idx = threadIdx.x; idx < groups * 8; idx += (int)blockDim.x) {
+    const int c = idx / groups, tok0 = (idx - c * groups) * 4;  // token group fastest: consecutive lanes write consecutive
+    f16x8 h[4];                                                  // 8-byte pieces of one feature row of the transposed image
 #pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
-      if (tok < L) h = load8(src + (size_t)tok * ld + 8 * c);
-      *reinterpret_cast<f16x8*>(rowm + tok * AF_ROW + 8 * c) = h;
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[q][j] = (_Float16)0.f;
+      if (tok0 + q < L) h[q] = load8(src + (size_t)(tok0 + q) * ld + 8 * c);
     }
-  if (tr)  // token fastest: the eight ds_write_b16 of a lane group go to consecutive halves of one feature row
-    for (int idx = threadIdx.x; idx < Lp * 8; idx += (int)blockDim.x) {
-      const int c = idx / Lp, tok = idx - c * Lp;
-      f16x8 h;
+    if (rowm) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (_Float16)0.f;
-      if (tok < L) h = load8(src + (size_t)tok * ld + 8 * c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) tr[(8 * c + j) * TP + tok] = h[j];
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f16x8*>(rowm + (tok0 + q) * AF_ROW + 8 * c) = h[q];
     }
+    if (tr) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<f16x4*>(tr + (8 * c + j) * TP + tok0) = f16x4{h[0][j], h[1][j], h[2][j], h[3][j]};
+    }
+  }
 }
 
 // The wave's own 32 rows as MFMA operands: frag[s] = row (t0 + lane & 31), features 16 s + 8 (lane >> 5) .. + 7.
