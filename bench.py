@@ -696,9 +696,9 @@ def cfg5_golden_check(dev, args):
     rows = int(sum(np.array_equal(top5[i], z["eval_top5"][i]) for i in range(B)))
     return model, tr, cfg, {
         "top5_match": rows == B, "top5_rows_matching": rows, "rows": B, "top1_match": bool((top5[:, 0] == z["eval_top5"][:, 0]).all()),
-        "max_abs_logit_err": round(err, 6), "tolerance": 5e-2,
+        "max_abs_logit_err": round(err, 6), "tolerance": 2e-2,
         "golden": "tests/golden/vitl14_full_step.npz (fp64 oracle; full-depth ViT-L/14, 4 images x 8 captions; the fp16 storage "
-                  "mode's stated budget is 5e-2 on 100 x cosine logits, tests/test_golden_gpu.py)"}
+                  "mode's stated budget is 2e-2 on 100 x cosine logits, tests/test_golden_gpu.py)"}
 
 
 def cfg5_leg(dev, args, lib):

@@ -182,7 +182,8 @@ size_t clipfs_attention_lse_floats(int batch, int seq, int heads);
 int clipfs_attention_f16_fwd(const void* qkv, int qkv_f16, float* out, void* out16, float* lse, int batch, int seq,
                              int heads, int causal, void* stream);
 /* dqkv from (qkv, dout, out, lse) of clipfs_attention_f16_fwd; work: batch*heads*seq floats (D_i = dO_i . O_i).
- * out16 / dqkv16 (may be NULL): f16 copies of out / dqkv, the A operands of the GEMMs that follow.
+ * out16 / dqkv16 (may be NULL): f16 copies of out / dqkv, the A operands of the GEMMs that follow; with dqkv16 given,
+ * dqkv itself may be NULL (fp16 storage mode: every consumer reads the f16 image, see clipfs_lora_bwd_f16dy).
  * qkv_f16 != 0: qkv is an f16 tensor [B*L, 3*d] (the QKV GEMM's f16 output: fp16 storage), else fp32. */
 int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const float* dout, const float* out, const float* lse,
                              float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads, int causal,
@@ -209,6 +210,14 @@ int clipfs_lora_bwd(const float* dy, const float* x, const float* t, const float
                     float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
                     int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
                     uint32_t drow0, float* work, void* stream);
+/* The same with dy given as its f16 image [rows, nseg*segw] (fp16 storage mode: the tensor the dgrad GEMM consumes), so
+ * that the two passes over dy move half the bytes and the fp32 dy need not exist.  Matrix-core kernels only:
+ * clipfs_lora_bwd_f16dy_ok(width, segw, r, nseg) != 0 says a shape is covered (r <= 16, width % 128 == 0, ...). */
+int clipfs_lora_bwd_f16dy_ok(int width, int segw, int r, int nseg);
+int clipfs_lora_bwd_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B,
+                          float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
+                          int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
+                          uint32_t drow0, float* work, void* stream);
 
 /* --------------------------------------------------------- token assembly --
  * vit: x[b,0,:] = class_embedding + pos[0]; x[b, 1+P+i, :] = vpt[i]  (jclip/model.py:109-114,

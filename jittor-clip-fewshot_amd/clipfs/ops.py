@@ -218,6 +218,12 @@ def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_ba
     nwork = lib.clipfs_lora_bwd_work_floats(rows, width, r, nseg)
     work = torch.empty(nwork, device=x.device, dtype=torch.float32)
     dt = torch.empty(rows, nseg * r, device=x.device, dtype=torch.float32)
+    if dy.dtype == torch.float16:  # fp16 storage mode: the f16 image of the incoming gradient (matrix-core shapes only)
+        assert dy.is_contiguous()
+        check(lib.clipfs_lora_bwd_f16dy(_p(dy), _p(_f32(x)), _p(_f32(t)), _p(_f32(A)), _p(_f32(B)), _p(dt), _p(dA),
+                                        _p(dB), _p(dx), rows, width, width, r, nseg, seg_mask, scale, p, seed, stream_base,
+                                        row0, _p(work), _stream()), "lora_bwd_f16dy")
+        return dt
     check(lib.clipfs_lora_bwd(_p(_f32(dy)), _p(_f32(x)), _p(_f32(t)), _p(_f32(A)), _p(_f32(B)), _p(dt), _p(dA),
                               _p(dB), _p(dx), rows, width, width, r, nseg, seg_mask, scale, p, seed, stream_base,
                               row0, _p(work), _stream()), "lora_bwd")

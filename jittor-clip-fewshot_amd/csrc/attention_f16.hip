@@ -281,7 +281,7 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const TQ* __re
           f32x4 v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = acc[t][4 * g4 + j];
-          *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g4) = v;
+          if (dqkv) *reinterpret_cast<f32x4*>(op + 32 * t + 8 * g4) = v;
           if (dqkv16)
             *reinterpret_cast<f16x4*>(dqkv16 + ((size_t)b * L + q_tok) * ld + h * AF_HD + 4 * fh + 32 * t + 8 * g4) =
                 f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -377,8 +377,10 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const TQ* __r
             k4[j] = ak[t][4 * g4 + j];
             v4[j] = av[t][4 * g4 + j];
           }
-          *reinterpret_cast<f32x4*>(kp + 32 * t + 8 * g4) = k4;
-          *reinterpret_cast<f32x4*>(vp + 32 * t + 8 * g4) = v4;
+          if (dqkv) {
+            *reinterpret_cast<f32x4*>(kp + 32 * t + 8 * g4) = k4;
+            *reinterpret_cast<f32x4*>(vp + 32 * t + 8 * g4) = v4;
+          }
           if (dqkv16) {
             _Float16* k16 = dqkv16 + ((size_t)b * L + k_tok) * ld + d + h * AF_HD + 4 * fh + 32 * t + 8 * g4;
             *reinterpret_cast<f16x4*>(k16) = f16x4{(_Float16)k4[0], (_Float16)k4[1], (_Float16)k4[2], (_Float16)k4[3]};
@@ -458,9 +460,10 @@ extern "C" int clipfs_attention_f16_fwd(const void* qkv, int qkv_f16, float* out
 extern "C" int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const float* dout, const float* out, const float* lse,
                                         float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads, int causal,
                                         void* stream) {
-  CLIPFS_CHECK(check_af(qkv, dqkv, batch, seq, heads));
+  CLIPFS_CHECK(check_af(qkv, dqkv ? (const void*)dqkv : dqkv16, batch, seq, heads));  // the fp32 result is optional beside the f16 one
   CLIPFS_REQUIRE(dout && out && lse && work, "attention_f16_bwd: null pointer");
-  CLIPFS_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(out) && aligned16(dqkv), "attention_f16_bwd: misaligned pointer");
+  CLIPFS_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(out) && aligned16(dqkv) && aligned16(dqkv16),
+                 "attention_f16_bwd: misaligned pointer");
   return qkv_f16 ? af_bwd<_Float16>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, (hipStream_t)stream)
                  : af_bwd<float>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, (hipStream_t)stream);
 }

@@ -103,6 +103,23 @@ __device__ __forceinline__ void finish_tiles(const clipfs_gemm_args& g, int patc
   }
   if (g.a_mode == 0 && full_tile && (lora_mfma || !g.lora_t)) {
     const int ldc = g.ldc;
+    // Every per-element LOAD of the wave's tiles (residual rows, else the saved pre-activation) is issued before the
+    // first STORE: vmcnt retires in issue order, so a load queued behind a store also waits for that store's
+    // acknowledgement (microseconds under load) -- round 2 loaded tile (i, j)'s residual after tile (i, j-1)'s stores.
+    const bool pre_res = g.residual != nullptr, pre_aux = !pre_res && g.act == 2;
+    float pre[TM][TN][16];
+    if (pre_res || pre_aux) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mb = mw + i * 32 + 4 * fh, n = nw + j * 32 + fr;
+          const float* q = pre_res ? g.residual + (size_t)mb * g.ldres + n : g.aux_in + (size_t)mb * ldc + n;
+          const int ldq = pre_res ? g.ldres : ldc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pre[i][j][r] = q[((r & 3) + 8 * (r >> 2)) * ldq];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nw + j * 32 + fr;
@@ -123,20 +140,21 @@ __device__ __forceinline__ void finish_tiles(const clipfs_gemm_args& g, int patc
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = quick_gelu(v[r]);
         } else if (g.act == 2) {
-          const float* q = g.aux_in + base;
-          float u[16];
+          if (pre_aux) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * ldc];
+            for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad(pre[i][j][r]);
+          } else {  // act 2 together with a residual (not on the path): the pre-activation is loaded here
+            const float* q = g.aux_in + base;
+            float u[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad(u[r]);
+            for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * ldc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] *= quick_gelu_grad(u[r]);
+          }
         }
-        if (g.residual) {
-          const float* q = g.residual + (size_t)mb * g.ldres + n;
-          float u[16];
+        if (pre_res) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) u[r] = q[((r & 3) + 8 * (r >> 2)) * g.ldres];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += u[r];
+          for (int r = 0; r < 16; ++r) v[r] += pre[i][j][r];
         }
         if (g.act == 3) {
 #pragma unroll

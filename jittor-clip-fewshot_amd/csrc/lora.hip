@@ -259,6 +259,10 @@ static inline int lora_slice_rows(int rows) {
 bool lora_mfma_ok(int width, int segw, int r, int nseg);
 int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
                    float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, hipStream_t st);
+int lora_bwd_mfma_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
+                        float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
+                        float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
+                        void (*reduce)(const float*, float*, size_t, int, float, hipStream_t));
 int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                   float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
@@ -374,4 +378,25 @@ extern "C" int clipfs_lora_bwd(const float* dy, const float* x, const float* t, 
       return CLIPFS_EINVAL;
   }
 #undef CLIPFS_LORA_CASE
+}
+
+// fp16 storage mode: the incoming gradient dy is read from its f16 image (what the dgrad GEMM consumes anyway) -- half
+// the bytes of the two passes over dy, and the producer (clipfs_attention_f16_bwd) no longer has to write the fp32
+// tensor at all.  Matrix-core kernels only: clipfs_lora_bwd_f16dy_ok says whether a shape is covered.
+extern "C" int clipfs_lora_bwd_f16dy_ok(int width, int segw, int r, int nseg) {
+  return (use_lora_mfma() && lora_mfma_ok(width, segw, r, nseg) && segw == width) ? 1 : 0;
+}
+
+extern "C" int clipfs_lora_bwd_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B,
+                                     float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
+                                     int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
+                                     uint32_t drow0, float* work, void* stream) {
+  CLIPFS_REQUIRE(dy16 && x && t && A && B && dt && dA && dB && work, "lora_bwd_f16dy: null pointer");
+  CLIPFS_REQUIRE(rows > 0 && clipfs_lora_bwd_f16dy_ok(width, segw, r, nseg),
+                 "lora_bwd_f16dy: width %d segw %d r %d nseg %d is outside the matrix-core kernels", width, segw, r, nseg);
+  CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_bwd_f16dy: dropout p out of range");
+  CLIPFS_REQUIRE(aligned16(dy16) && aligned16(x) && aligned16(A) && aligned16(work) && (!dx || aligned16(dx)),
+                 "lora_bwd_f16dy: misaligned pointer");
+  return lora_bwd_mfma_f16dy(dy16, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base,
+                             drow0, work, (hipStream_t)stream, launch_reduce_slices);
 }

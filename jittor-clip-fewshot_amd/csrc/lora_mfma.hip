@@ -29,6 +29,17 @@ __device__ __forceinline__ f32x4 zero4() {
   return z;
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// fp16 storage mode: the incoming gradient is read from its f16 image (the dgrad GEMM's A operand): half the bytes
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ld4(const _Float16* p) {
+  const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+  f32x4 v;
+  v[0] = (float)h[0];
+  v[1] = (float)h[1];
+  v[2] = (float)h[2];
+  v[3] = (float)h[3];
+  return v;
+}
 
 // Sum the four waves' partial accumulators (the waves of a block split the reduction axis) through LDS; wave 0 gets
 // the total.  red: [4 waves][NACC][64 lanes] f32x4.
@@ -112,8 +123,8 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __rest
 }
 
 // dt = scale * dy_seg B_seg
-template <int NSEG>
-__global__ __launch_bounds__(256) void lora_dt_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ B,
+template <int NSEG, typename TY>
+__global__ __launch_bounds__(256) void lora_dt_mfma_kernel(const TY* __restrict__ dy, const float* __restrict__ B,
                                                            float* __restrict__ dt, int rows, int segw, int r,
                                                            unsigned seg_mask, float scale) {
   __shared__ f32x4 red[3 * NSEG * 64];
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256) void lora_dt_mfma_kernel(const float* __restri
   const int row0 = blockIdx.x * 16;
   const int m = min(row0 + li, rows - 1);
   const int cw = segw >> 2;
-  const float* dr = dy + (size_t)m * NSEG * segw + 4 * kg;
+  const TY* dr = dy + (size_t)m * NSEG * segw + 4 * kg;
   const int jj = min(li, r - 1);
   f32x4 acc[NSEG];
 #pragma unroll
@@ -165,7 +176,8 @@ __global__ __launch_bounds__(256) void lora_dt_mfma_kernel(const float* __restri
 
 // dB partials: part[slice][n][j] = sum_{m in slice} dy[m, n] t[m, seg(n) r + j].  One wave per (64 columns, slice);
 // lane i owns columns n0 + 4 i + e of MFMA tile e.
-__global__ __launch_bounds__(256) void lora_db_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ t,
+template <typename TY>
+__global__ __launch_bounds__(256) void lora_db_mfma_kernel(const TY* __restrict__ dy, const float* __restrict__ t,
                                                            float* __restrict__ part, int rows, int cols, int segw,
                                                            int nseg, int r, int rows_per_slice) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(256) void lora_db_mfma_kernel(const float* __restri
   const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
   const int s = n0 / segw;
   const int tw = nseg * r;
-  const float* dp = dy + n0 + 4 * li;
+  const TY* dp = dy + n0 + 4 * li;
   const float* tp = t + s * r + min(li, r - 1);
   f32x4 acc[4];
 #pragma unroll
@@ -367,8 +379,8 @@ int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width
   return launch_status();
 }
 
-template <int NSEG>
-static int lora_bwd_mfma_n(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
+template <int NSEG, typename TY>
+static int lora_bwd_mfma_n(const TY* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
                            float* dA, float* dB, float* dx, int rows, int width, int segw, int r, unsigned seg_mask,
                            float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
                            void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
@@ -376,10 +388,10 @@ static int lora_bwd_mfma_n(const float* dy, const float* x, const float* t, cons
   const int sr_b = lora_mfma_slice_rows(rows, cols / 64), slices_b = (rows + sr_b - 1) / sr_b;
   const int sr_a = lora_mfma_slice_rows(rows, width / 64), slices_a = (rows + sr_a - 1) / sr_a;
   const dim3 rgrid((rows + 15) / 16);
-  hipLaunchKernelGGL((lora_dt_mfma_kernel<NSEG>), rgrid, dim3(256), 0, st, dy, B, dt, rows, segw, r, seg_mask, scale);
+  hipLaunchKernelGGL((lora_dt_mfma_kernel<NSEG, TY>), rgrid, dim3(256), 0, st, dy, B, dt, rows, segw, r, seg_mask, scale);
   CLIPFS_CHECK(launch_status());
   float* part_b = work;
-  hipLaunchKernelGGL(lora_db_mfma_kernel, dim3((cols + 255) / 256, slices_b), dim3(256), 0, st, dy, t, part_b, rows, cols,
+  hipLaunchKernelGGL(lora_db_mfma_kernel<TY>, dim3((cols + 255) / 256, slices_b), dim3(256), 0, st, dy, t, part_b, rows, cols,
                      segw, NSEG, r, sr_b);
   CLIPFS_CHECK(launch_status());
   const size_t nb = (size_t)cols * r;
@@ -417,10 +429,23 @@ int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* 
                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
                   void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
   if (nseg == 1)
-    return lora_bwd_mfma_n<1>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
-                              work, st, reduce);
-  return lora_bwd_mfma_n<3>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
-                            work, st, reduce);
+    return lora_bwd_mfma_n<1, float>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
+                                     work, st, reduce);
+  return lora_bwd_mfma_n<3, float>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
+                                   work, st, reduce);
+}
+
+// the same with dy given as its f16 image [rows, nseg * segw] (fp16 storage mode)
+int lora_bwd_mfma_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
+                        float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
+                        float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
+                        void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
+  const _Float16* dy = reinterpret_cast<const _Float16*>(dy16);
+  if (nseg == 1)
+    return lora_bwd_mfma_n<1, _Float16>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
+                                        drow0, work, st, reduce);
+  return lora_bwd_mfma_n<3, _Float16>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
+                                      drow0, work, st, reduce);
 }
 
 }  // namespace clipfs

@@ -378,9 +378,12 @@ static int tower_bwd_range(const clipfs_tower* t, float* dx, int batch, const fl
     }
     // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
     const void* dqkv16_ready = nullptr;
+    // fp16 storage mode: the dgrad GEMM and (matrix-core shapes) the adapter backward read the f16 image of dqkv, so the
+    // attention backward does not write the fp32 tensor at all (404 MB per ViT-L/14 block at 128 images)
+    const bool dy16 = f16_attention(t) && dqkv16 && (!qkv_mask || clipfs_lora_bwd_f16dy_ok(d, d, r, 3));
     if (f16_attention(t)) {
-      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dqkv, dqkv16, dh, batch,
-                                            t->seq, t->heads, t->causal, st));
+      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dy16 ? nullptr : dqkv, dqkv16,
+                                            dh, batch, t->seq, t->heads, t->causal, st));
       dqkv16_ready = dqkv16;
     } else
       CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
@@ -391,9 +394,14 @@ static int tower_bwd_range(const clipfs_tower* t, float* dx, int batch, const fl
                         0.f, st, CHAIN_NONE, dqkv16_ready));
     if (qkv_mask) {
       CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);
-      CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
-                                   b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
-                                   t->lora_dropout, seed, ds, t->dropout_row0, work, st));
+      if (dy16)
+        CLIPFS_CHECK(clipfs_lora_bwd_f16dy(dqkv16, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
+                                           b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
+                                           t->lora_dropout, seed, ds, t->dropout_row0, work, st));
+      else
+        CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
+                                     b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
+                                     t->lora_dropout, seed, ds, t->dropout_row0, work, st));
     }
     if (need_dx) {
       if (h16)
@@ -472,15 +480,16 @@ extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, 
   float* dt = scratch + SC.dt;
   float* work = scratch + SC.work;
   CLIPFS_CHECK(clipfs_scatter_rows(datt_s, rows, datt, batch, seq, d, st));
+  const unsigned qkv_mask = b.lora_a_qkv ? (b.lora_mask & 7u) : 0u;
   const void* dqkv16_ready = nullptr;
+  void* dqkv16 = (f16_attention(t) && cx.a16) ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
+  const bool dy16 = dqkv16 && (!qkv_mask || clipfs_lora_bwd_f16dy_ok(d, d, r, 3));  // as in tower_bwd_range
   if (f16_attention(t)) {
-    void* dqkv16 = cx.a16 ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves (tower_bwd_range's slot)
-    CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dqkv, dqkv16, dh, batch, seq,
-                                          t->heads, t->causal, st));
+    CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dy16 ? nullptr : dqkv, dqkv16,
+                                          dh, batch, seq, t->heads, t->causal, st));
     dqkv16_ready = dqkv16;
   } else
     CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, seq, t->heads, t->causal, st));
-  const unsigned qkv_mask = b.lora_a_qkv ? (b.lora_mask & 7u) : 0u;
   const uint32_t ds = t->dropout_stream0 + 4u * (uint32_t)l;
   const bool need_dx = !(l == 0 && stop_at_input);
   if (need_dx)
@@ -488,9 +497,14 @@ extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, 
                       0, 0.f, st, CHAIN_NONE, dqkv16_ready));
   if (qkv_mask) {
     CLIPFS_REQUIRE(b.g_lora_a_qkv && b.g_lora_b_qkv, "tower_bwd: block %d LoRA gradient slots missing", l);
-    CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv, b.g_lora_b_qkv,
-                                 need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale, t->lora_dropout,
-                                 t->dropout_seed, ds, t->dropout_row0, work, st));
+    if (dy16)
+      CLIPFS_CHECK(clipfs_lora_bwd_f16dy(dqkv16, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
+                                         b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
+                                         t->lora_dropout, t->dropout_seed, ds, t->dropout_row0, work, st));
+    else
+      CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv, b.g_lora_b_qkv,
+                                   need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale, t->lora_dropout,
+                                   t->dropout_seed, ds, t->dropout_row0, work, st));
   }
   if (!need_dx) return CLIPFS_OK;
   CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_in, d, b.ln1_g, sv + SL.stat1, sv + SL.stat1 + M, nullptr, dx, d, M, d, st));

@@ -240,11 +240,12 @@ def l14_signs(n, seed):
     return rng.randint(0, 2, size=n).astype(np.float64) * 2 - 1
 
 
-# fp16 storage mode at FULL depth (24 + 12 blocks), stated budget against the fp64 oracle -- measured on MI355X:
-# see the assertion messages / DESIGN.md section 4 for the observed values
-L14_FP16_LOGIT_TOL = 5e-2      # on 100 x cosine logits
-L14_FP16_GRAD_REL_L2 = 5e-2    # ||g - g64|| / ||g64|| over the stored every-8th-element sample
-L14_FP16_MIN_TOP5_ROWS = 3     # of 4 images: rows whose top-5 label LIST equals the oracle's
+# fp16 storage mode at FULL depth (24 + 12 blocks): the STATED budget against the fp64 oracle.  Measured on MI355X (round 3,
+# printed by the test): logits 4.7e-3 (eval) / 3.3e-3 (train, dropout 0.25), unit features 1.0e-4, top-5 lists 4 / 4 rows,
+# gradient 2.5e-3 relative L2 (largest entry off by 4.1e-3 of 2.13), loss 9.6e-4 -- the budget leaves ~4x head-room.
+L14_FP16_LOGIT_TOL = 2e-2      # on 100 x cosine logits
+L14_FP16_GRAD_REL_L2 = 1e-2    # ||g - g64|| / ||g64|| over the stored every-8th-element sample
+L14_FP16_MIN_TOP5_ROWS = 4     # of 4 images: rows whose top-5 label LIST equals the oracle's (gaps >= 0.1 between neighbours)
 
 
 def test_vitl14_full_depth_vs_golden(dev, golden_dir):

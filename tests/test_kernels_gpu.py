@@ -315,6 +315,28 @@ def test_adamw(dev):
     _close(md, m, 1e-8, "adamw m")
 
 
+def test_lora_bwd_from_f16_gradient_image(dev):
+    """fp16 storage mode reads the incoming gradient of the adapter backward from its f16 image (clipfs_lora_bwd_f16dy): on
+    an f16-exact dy it must give bitwise the results of the fp32 entry point (f16 -> f32 is exact, same kernels)."""
+    from clipfs import _lib, ops
+    rows, width, r, nseg, seed = 1000, 256, 16, 3, 0x77
+    assert _lib.load().clipfs_lora_bwd_f16dy_ok(width, width, r, nseg) == 1
+    assert _lib.load().clipfs_lora_bwd_f16dy_ok(192, 192, r, nseg) == 0  # outside the matrix-core kernels
+    x = _rand(rows, width, seed=1).float().to(dev)
+    A = _rand(nseg * r, width, seed=2, scale=width ** -0.5).float().to(dev)
+    B = _rand(nseg * width, r, seed=3, scale=0.1).float().to(dev)
+    dy16 = _rand(rows, nseg * width, seed=4).half().to(dev)
+    t = ops.lora_down(x, A, r, nseg, p=0.25, seed=seed, stream_base=3)
+    outs = []
+    for dy in (dy16.float(), dy16):
+        dA, dB, dx = torch.zeros_like(A), torch.zeros_like(B), torch.ones_like(x)
+        dt = ops.lora_bwd(dy, x, t, A, B, dA, dB, dx=dx, scale=0.25, p=0.25, seed=seed, stream_base=3)
+        outs.append((dt, dA, dB, dx))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][1].abs().max() > 0 and outs[0][2].abs().max() > 0
+
+
 # ------------------------------------------------------------------ MTA
 @pytest.mark.parametrize("V,d,Cn", [(65, 512, 403), (17, 64, 10)])
 def test_mta(dev, V, d, Cn):
