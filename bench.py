@@ -515,10 +515,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (tower GEMMs as split-bf16 x3 MFMA, fp32 accumulate)", "fp16": "f16 operands in the tower GEMMs, fp32 accumulate"}[args.precision], "data": "synthetic",
-            "config": {"workload": "cfg-2: ViT-B/32 + rank-4 LoRA(q,k,v; 12 text + 12 vision blocks; shipped "
-                                   "lora_weights.pkl) + 4 text-prompt tokens; run_lora train step = text tower "
-                                   "fwd+bwd on 403 captions + image tower fwd+bwd + 100*cos CE + AdamW"
-                       if not args.forward_only else "ViT-B/32 image tower forward only (diagnostic)",
+            "config": {"workload": ("ViT-B/32 image tower forward only (diagnostic)" if args.forward_only else
+                                    "cfg-5 shapes: ViT-L/14 + rank-16 LoRA(q,k,v; 12 text + 21 vision blocks, synthetic adapters) + 4 "
+                                    "text-prompt tokens; run_lora train step, fp16 storage mode when --precision fp16"
+                                    if args.model == "l14" else
+                                    "cfg-2: ViT-B/32 + rank-4 LoRA(q,k,v; 12 text + 12 vision blocks; shipped "
+                                    "lora_weights.pkl) + 4 text-prompt tokens; run_lora train step = text tower "
+                                    "fwd+bwd on 403 captions + image tower fwd+bwd + 100*cos CE + AdamW"),
                        "global_batch": gb, "images_per_rank": n_img_local, "captions": args.classes,
                        "last_block": "dense (CLIPFS_DENSE_BWD=1)" if os.environ.get("CLIPFS_DENSE_BWD", "0") not in ("", "0")
                        else "after its attention, forward and backward on one row per sequence (the class / EOT row: the only "
