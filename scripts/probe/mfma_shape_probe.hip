@@ -133,6 +133,7 @@ static void run(const char* name, const float* src, float* out, unsigned long lo
 // global_load_lds_dwordx4 (24 KiB per workgroup, the 64 x 128 x 32 tile's operands), waits for them at the end of the
 // K-step and passes a barrier.  The source window decides where the bytes come from: `span` bytes per XCD-group of
 // workgroups, walked cyclically (small: every line an L2 hit; larger than 4 MiB per XCD: Infinity Cache; > 256 MiB: HBM).
+template <int NDMA>
 __global__ __launch_bounds__(256) void probe_dma(const float* __restrict__ src, float* __restrict__ out, unsigned long long* stamps,
                                                  int iters, size_t span_floats, int share) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (64 + 128) * 32];
@@ -145,23 +146,23 @@ __global__ __launch_bounds__(256) void probe_dma(const float* __restrict__ src, 
   f32x16 acc0 = {}, acc1 = {};
   // share = 1: every workgroup of the launch walks the SAME window (operands shared chip-wide, like weights);
   // share = 0: each workgroup its own slice of the window
-  const size_t wg_off = share ? 0 : ((size_t)blockIdx.x * 6151 * 256) % span_floats;
+  const size_t wg_off = share ? 0 : ((size_t)blockIdx.x * 6151 * 256) & (span_floats - 1);
   unsigned long long t0 = 0, r0 = 0;
   if (tid == 0) {
     t0 = __builtin_amdgcn_s_memtime();
     r0 = __builtin_amdgcn_s_memrealtime();
   }
   const int uw = __builtin_amdgcn_readfirstlane(wave);
-  size_t pos = wg_off;
+  // span_floats is a power of two: the walk wraps with a mask (no 64-bit division in the loop)
+  const size_t mask = span_floats - 1;
+  size_t pos = wg_off + (size_t)uw * NDMA * 256 + lane * 4;
   for (int it = 0; it < iters; ++it) {
     float* st = lds + ((it + 1) & 1) * (64 + 128) * 32;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const size_t o = (pos + (size_t)(uw * 6 + i) * 256 + lane * 4) % span_floats;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (o & ~(size_t)3)),
+    for (int i = 0; i < NDMA; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((pos + (size_t)i * 256) & mask)),
                                        (__attribute__((address_space(3))) void*)(st + (uw * 6 + i) * 256), 16, 0, 0);
-    }
-    pos += 24 * 256;
+    pos += 4 * NDMA * 256;
     const float* s = lds + (it & 1) * (64 + 128) * 32;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -187,18 +188,19 @@ __global__ __launch_bounds__(256) void probe_dma(const float* __restrict__ src, 
   out[blockIdx.x * 256 + tid] = sink;
 }
 
+template <int NDMA>
 static void run_dma(const char* name, const float* src, float* out, unsigned long long* stamps, int wgs, int iters, size_t span_bytes,
                     int share) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   for (int w = 0; w < 3; ++w)
-    hipLaunchKernelGGL(probe_dma, dim3(wgs), dim3(256), 0, 0, src, out, stamps, iters, span_bytes / 4, share);
+    hipLaunchKernelGGL(probe_dma<NDMA>, dim3(wgs), dim3(256), 0, 0, src, out, stamps, iters, span_bytes / 4, share);
   hipDeviceSynchronize();
   std::vector<double> tf, clk;
   for (int rep = 0; rep < 5; ++rep) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(probe_dma, dim3(wgs), dim3(256), 0, 0, src, out, stamps, iters, span_bytes / 4, share);
+    hipLaunchKernelGGL(probe_dma<NDMA>, dim3(wgs), dim3(256), 0, 0, src, out, stamps, iters, span_bytes / 4, share);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -215,7 +217,7 @@ static void run_dma(const char* name, const float* src, float* out, unsigned lon
   }
   std::sort(tf.begin(), tf.end());
   std::sort(clk.begin(), clk.end());
-  const double tbs = (double)wgs * iters * 24576.0 / (((double)wgs * 4 * iters * 32.0 * 4096.0) / (tf[2] * 1e12)) / 1e12;
+  const double tbs = (double)wgs * iters * (4096.0 * NDMA) / (((double)wgs * 4 * iters * 32.0 * 4096.0) / (tf[2] * 1e12)) / 1e12;
   printf("%-58s %7.1f TFLOP/s   clock %5.3f GHz   %5.1f FLOP/clk/CU   stream %5.2f TB/s\n", name, tf[2], clk[2],
          tf[2] * 1e12 / (clk[2] * 1e9) / 256.0, tbs);
 }
@@ -238,11 +240,15 @@ int main() {
   if (getenv("PROBE_DMA")) {
     const int it2 = 4000;
     run<0, true>("32x32x2 + LDS reads, no global stream", src, out, stamps, wgs, it2);
-    run_dma("+ LDS-DMA, every WG the same 1 MiB window (L2 hits)", src, out, stamps, wgs, it2, (size_t)1 << 20, 1);
-    run_dma("+ LDS-DMA, 16 MiB window shared (L2 / Infinity Cache)", src, out, stamps, wgs, it2, (size_t)16 << 20, 1);
-    run_dma("+ LDS-DMA, own slices of a 24 MiB window (~L2 capacity)", src, out, stamps, wgs, it2, (size_t)24 << 20, 0);
-    run_dma("+ LDS-DMA, own slices of a 192 MiB window (Infinity Cache)", src, out, stamps, wgs, it2, (size_t)192 << 20, 0);
-    run_dma("+ LDS-DMA, own slices of a 2 GiB window (HBM)", src, out, stamps, wgs, it2, (size_t)2048 << 20, 0);
+    run_dma<6>("+ 6 LDS-DMA / wave / K-step (64x128 tile), 1 MiB shared window (L2)", src, out, stamps, wgs, it2, (size_t)1 << 20, 1);
+    run_dma<4>("+ 4 LDS-DMA (128x128-tile bytes per FLOP), 1 MiB shared (L2)", src, out, stamps, wgs, it2, (size_t)1 << 20, 1);
+    run_dma<3>("+ 3 LDS-DMA (128x256-tile bytes per FLOP), 1 MiB shared (L2)", src, out, stamps, wgs, it2, (size_t)1 << 20, 1);
+    run_dma<2>("+ 2 LDS-DMA (256x256-tile bytes per FLOP), 1 MiB shared (L2)", src, out, stamps, wgs, it2, (size_t)1 << 20, 1);
+    run_dma<6>("+ 6 LDS-DMA, own slices of a 16 MiB window (L2 capacity)", src, out, stamps, wgs, it2, (size_t)16 << 20, 0);
+    run_dma<6>("+ 6 LDS-DMA, own slices of a 128 MiB window (Infinity Cache)", src, out, stamps, wgs, it2, (size_t)128 << 20, 0);
+    run_dma<3>("+ 3 LDS-DMA, own slices of a 128 MiB window (Infinity Cache)", src, out, stamps, wgs, it2, (size_t)128 << 20, 0);
+    run_dma<6>("+ 6 LDS-DMA, own slices of a 2 GiB window (HBM)", src, out, stamps, wgs, it2, (size_t)2048 << 20, 0);
+    run_dma<3>("+ 3 LDS-DMA, own slices of a 2 GiB window (HBM)", src, out, stamps, wgs, it2, (size_t)2048 << 20, 0);
     run<0, true>("32x32x2 + LDS reads, no global stream (again)", src, out, stamps, wgs, it2);
     return 0;
   }
