@@ -390,6 +390,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
 // T16: the accumulators are 8 x 4 tiles of v_mfma_f32_16x16x32_f16 (lane: column l & 15, rows 4 (l >> 4) + r); a store
 // instruction then covers four row groups 4 rows apart, which all fall on the same 16 banks of a 1 KiB-pitch image -- the
 // 16-float column blocks are XORed with the row group ((row >> 2) & 3) on both sides.
+#ifdef CLIPFS_STAMPS
+__device__ unsigned long long clipfs_f16_stamps[8192 * 10];
+#define F16_STAMP(i)                                                                                  \
+  do {                                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                      \
+      clipfs_f16_stamps[blockIdx.x * 10 + (i)] = __builtin_amdgcn_s_memtime();                         \
+      if ((i) == 1) clipfs_f16_stamps[blockIdx.x * 10 + 4] = __builtin_amdgcn_s_memrealtime();        \
+      if ((i) == 2) clipfs_f16_stamps[blockIdx.x * 10 + 5] = __builtin_amdgcn_s_memrealtime();        \
+    }                                                                                                 \
+  } while (0)
+}  // namespace clipfs
+extern "C" int clipfs_debug_read_f16_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clipfs::clipfs_f16_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+namespace clipfs {
+#else
+#define F16_STAMP(i) do {} while (0)
+#endif
+
 // Epilogue of the 256 x 256 kernels through LDS: the accumulators are transposed through the (now idle) ring in two
 // passes of 128 tile rows, then every thread owns 4 consecutive columns of 16 rows of the pass and does row-major
 // 16-byte accesses.
@@ -409,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const F16Params p) {
 // 67 -> 31 k (f16 result x saved pre-activation); cfg-5 step 110.4 -> 102.8 ms.  Tried and dropped: starting the first
 // round's workgroups 0-3 delay steps apart so that the CUs' epilogue bursts do not coincide (no change up to 8 k
 // cycles per step: the epilogue is bound per CU, not by a chip-wide burst).
-template <bool T16, class AccT>
+template <bool T16, bool WIDE, class AccT>
 __device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, AccT& acc, float* lds, int m0, int n0, int wm, int wn,
                                                  int tid) {
   const clipfs_gemm_args& g = p.a;
@@ -506,16 +525,105 @@ __device__ __forceinline__ void f16_epilogue_lds(const F16Params& p, AccT& acc, 
     }
   };
 
+  // ---- f16-only result (the QKV, c_fc and d(c_proj) products: 69 % of the tower's GEMM FLOPs): 8 columns per thread ----
+  // The row loop is bound by the NUMBER of vector-memory instructions (stamps: ~40 cycles per wave-store whatever its
+  // width), so a thread takes 8 consecutive columns of 8 rows per pass: one 16-byte store per row instead of two 8-byte
+  // ones (and one 16-byte load of the saved pre-activation).  Same arithmetic per element.
+  typedef _Float16 f16x8e __attribute__((ext_vector_type(8)));
+  // (WIDE is chosen on the host -- f16_wide_epilogue_ok -- and is a template parameter so that the two paths do not
+  // share a register allocation: as one runtime branch the fp32-result path spilled and ran 3x slower)
+  if constexpr (WIDE) {
+    constexpr int RW = 8;                      // rows per thread and pass
+    const int c8 = tid & 31, r16 = tid >> 5;   // columns n8 .. n8 + 7 of staging rows r16 + 16 k
+    const int n8 = n0 + 8 * c8;
+    const bool n8_ok = n8 < N;
+    const int n8c = n8_ok ? n8 : 0;
+    f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bb = ba;
+    if (g.bias) {
+      ba = *reinterpret_cast<const f32x4*>(g.bias + n8c);
+      bb = *reinterpret_cast<const f32x4*>(g.bias + n8c + 4);
+    }
+    f32x4 lw0[RW], lw1[RW];  // act 2: eight halves of the saved pre-activation per row
+    auto issue8 = [&](int ps, f32x4 (&r)[RW]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        const int m = min(m0 + tile_row(ps, r16 + 16 * k), Mend - 1);
+        r[k] = *reinterpret_cast<const f32x4*>(aux16 + (size_t)m * ldc + n8c);
+      }
+    };
+    auto finish8 = [&](int ps, const f32x4 (&r)[RW]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kb = 0; kb < RW; kb += 2) {
+        f32x4 va[2], vb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = r16 + 16 * (kb + j);
+          const int sw = T16 ? 16 * ((row >> 2) & 3) : 0;
+          va[j] = *reinterpret_cast<const f32x4*>(lds + row * 256 + ((8 * c8) ^ sw));
+          vb[j] = *reinterpret_cast<const f32x4*>(lds + row * 256 + ((8 * c8 + 4) ^ sw));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int m = m0 + tile_row(ps, r16 + 16 * (kb + j));
+          const bool ok = n8_ok && m < Mend;
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[e] = g.bias ? g.alpha * va[j][e] + ba[e] : g.alpha * va[j][e];
+            x[4 + e] = g.bias ? g.alpha * vb[j][e] + bb[e] : g.alpha * vb[j][e];
+          }
+          const size_t o = (size_t)m * ldc + n8;
+          if (g.act == 1) {
+            if (g.aux_out && ok) {
+              f16x8e h;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+              *reinterpret_cast<f16x8e*>(reinterpret_cast<_Float16*>(g.aux_out) + o) = h;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = quick_gelu_fast(x[e]);
+          } else if (act2) {
+            const f16x8e u = __builtin_bit_cast(f16x8e, r[kb + j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= quick_gelu_grad_fast((float)u[e]);
+          }
+          if (ok) {
+            f16x8e h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+            *reinterpret_cast<f16x8e*>(p.C16 + o) = h;
+          }
+        }
+      }
+    };
+    if (act2) issue8(0, lw0);
+    stage(0);
+    F16_STAMP(6);
+    __builtin_amdgcn_sched_barrier(0);
+    if (act2) issue8(1, lw1);
+    __builtin_amdgcn_sched_barrier(0);
+    finish8(0, lw0);
+    F16_STAMP(7);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(1);
+    F16_STAMP(8);
+    finish8(1, lw1);
+    return;
+  } else {
   const bool any_loads = has_res || act2;
   if (any_loads) issue_loads(0, ld0);  // in flight across the staging of pass 0
   stage(0);
+  F16_STAMP(6);
   __builtin_amdgcn_sched_barrier(0);
   if (any_loads) issue_loads(1, ld1);  // half of the accumulators are dead now; still ahead of every store
   __builtin_amdgcn_sched_barrier(0);
   finish(0, ld0);
+  F16_STAMP(7);
   __builtin_amdgcn_sched_barrier(0);
   stage(1);
+  F16_STAMP(8);
   finish(1, ld1);
+  }
 }
 
 // ---- 256 x 256 "ping-pong" kernel ---------------------------------------------------------------------------------
@@ -658,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
   if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
   if constexpr (RM) {
     f16_lora_step<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
-    f16_epilogue_lds<false>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
+    f16_epilogue_lds<false, false>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
   } else {
     f16_finish<TM, TN>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, m0 + BM <= Mend && n0 + BN <= N, lane);
   }
@@ -688,26 +796,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_pp_kernel(const F16Params p) 
 //        in (t,2), restaged in (t+1,1); A1 read in (t,3), restaged in (t+1,2).  A read of phase G is complete
 //        (lgkmcnt(0)) before the reader's second barrier of that phase (<= #2G+3); the restage of phase G+2 is issued
 //        after #2G+4.
-#ifdef CLIPFS_STAMPS
-__device__ unsigned long long clipfs_f16_stamps[8192 * 6];
-#define F16_STAMP(i)                                                                                  \
-  do {                                                                                                \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                                      \
-      clipfs_f16_stamps[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memtime();                         \
-      if ((i) == 1) clipfs_f16_stamps[blockIdx.x * 6 + 4] = __builtin_amdgcn_s_memrealtime();        \
-      if ((i) == 2) clipfs_f16_stamps[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();        \
-    }                                                                                                 \
-  } while (0)
-}  // namespace clipfs
-extern "C" int clipfs_debug_read_f16_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clipfs::clipfs_f16_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
-}
-namespace clipfs {
-#else
-#define F16_STAMP(i) do {} while (0)
-#endif
 
-template <bool T16>
+template <bool T16, bool WIDE>
 __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   F16_STAMP(0);
@@ -888,7 +978,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16_ph_kernel(const F16Params p) 
   if (wm == 0) __builtin_amdgcn_s_barrier();  // group 0 catches the extra barrier of group 1
   F16_STAMP(2);
   if constexpr (!T16) f16_lora_step<4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, n0, lane);
-  f16_epilogue_lds<T16>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
+  f16_epilogue_lds<T16, WIDE>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, tid);
   F16_STAMP(3);
 }
 
@@ -913,9 +1003,11 @@ static int launch_f16_pp(F16Params& p, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_pp_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel<true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel<true, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel<false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel<true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_ph_kernel<false, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
@@ -926,10 +1018,17 @@ static int launch_f16_pp(F16Params& p, hipStream_t stream) {
   // is the default; 32x32x16 stays as CLIPFS_F16_PHASED=2.
   const bool phased = p.row_major_epilogue && ph_cfg != 0 && (p.a.K % 64) == 0 && p.a.K >= 128;
   const bool shape16 = ph_cfg != 2;
-  if (phased && shape16)
-    hipLaunchKernelGGL(gemm_f16_ph_kernel<true>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  // f16-only result without a residual: the 8-columns-per-thread epilogue (16-byte stores / pre-activation loads)
+  const clipfs_gemm_args& ga = p.a;
+  const bool wide = !ga.C && p.C16 && !ga.residual && (ga.N & 7) == 0 && (ga.ldc & 7) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(p.C16) | reinterpret_cast<uintptr_t>(ga.aux_out) |
+                      reinterpret_cast<uintptr_t>(ga.aux_in) | reinterpret_cast<uintptr_t>(ga.bias)) & 15) == 0;
+  if (phased && shape16 && wide)
+    hipLaunchKernelGGL((gemm_f16_ph_kernel<true, true>), dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+  else if (phased && shape16)
+    hipLaunchKernelGGL((gemm_f16_ph_kernel<true, false>), dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   else if (phased)
-    hipLaunchKernelGGL(gemm_f16_ph_kernel<false>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm_f16_ph_kernel<false, false>), dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   else if (p.row_major_epilogue)
     hipLaunchKernelGGL(gemm_f16_pp_kernel<true>, dim3(mb * p.n_blocks_n), dim3(512), lds, stream, p);
   else

@@ -47,13 +47,14 @@ for name, N, K, mode in [("qkv  C16 only", 3072, 1024, "c16"), ("out  fp32 C", 1
     torch.cuda.synchronize()
     ev = e0.elapsed_time(e1) * 1e3
     n = (Mi // 256) * (N // 256)
-    buf = (ctypes.c_ulonglong * (n * 6))()
-    assert raw.clipfs_debug_read_f16_stamps(buf, n * 6) == 0
-    st = np.array(buf, dtype=np.float64).reshape(n, 6)
+    buf = (ctypes.c_ulonglong * (n * 10))()
+    assert raw.clipfs_debug_read_f16_stamps(buf, n * 10) == 0
+    st = np.array(buf, dtype=np.float64).reshape(n, 10)
     pro, kl, ep = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
     rt = st[:, 5] - st[:, 4]
     clock = np.median(kl[rt > 0] / rt[rt > 0]) * 0.1
     ideal = K / 64 * 4 * 16 * 16  # 16x16x32: 16 cycles per MFMA on one SIMD, 2 waves per SIMD -> 2 x 64 MFMAs x 16 cyc / 2 ... per wave: 64 MFMAs per K-tile
     print(f"{name:16s} M={Mi} N={N} K={K} tiles={n} event {ev:7.1f} us {2.0 * Mi * N * K / ev / 1e6:7.1f} TF | clock {clock:5.3f} GHz | "
           f"prologue {np.median(pro):6.0f} | K loop {np.median(kl):7.0f} cyc ({np.median(kl) / (K / 64):5.0f}/K-tile; MFMA bound 2048) | "
-          f"epilogue {np.median(ep):6.0f} cyc = {np.median(ep) / np.median(st[:, 3] - st[:, 0]) * 100:4.1f}% of the tile")
+          f"epilogue {np.median(ep):6.0f} cyc = {np.median(ep) / np.median(st[:, 3] - st[:, 0]) * 100:4.1f}% of the tile "
+          f"[stage0 {np.median(st[:, 6] - st[:, 2]):5.0f} | rows0 {np.median(st[:, 7] - st[:, 6]):5.0f} | stage1 {np.median(st[:, 8] - st[:, 7]):5.0f} | rows1 {np.median(st[:, 3] - st[:, 8]):5.0f}]")
