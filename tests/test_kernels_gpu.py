@@ -430,7 +430,10 @@ def test_gemm_f16_mode(dev):
 def test_gemm_f16_operands(M, N, K, lora_r, act):
     """f16 x f16 kernel (cfg-5 storage mode): both operands f16 in HBM, fp32 accumulate; f16 products are exact in
     fp32, so against an fp32 matmul of the same rounded operands only the summation order differs (tolerance 2e-5
-    relative to the row scale); the f16 output copy is the fp32 result rounded once (2^-11 relative)."""
+    relative to the row scale); the f16 output copy is the fp32 result rounded once (2^-11 relative).
+    The reference here is torch's matmul ON THE GPU (rocBLAS: an independent implementation, not the CPU oracle);
+    test_gemm_f16_lds_epilogue_modes checks the same kernel against CPU fp64.  fp32 aux tensors / act 2 with a residual
+    (this test) go through the register-epilogue kernel, f16 aux tensors (the tower) through the LDS epilogue."""
     from clipfs import ops
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).cuda()
@@ -468,6 +471,52 @@ def test_gemm_f16_operands(M, N, K, lora_r, act):
     assert (out16.float() - ref).abs().max().item() <= 1e-3 * scale
     if act == 1:
         assert (aux_out - pre).abs().max().item() <= 2e-5 * pre.abs().max().item() + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16_bias", "f16_gelu_aux", "f16_gelu_grad", "f32_residual"])
+@pytest.mark.parametrize("M,N,K", [(2048, 2560, 128), (2048 + 40, 2560, 192)])  # 80 tiles of 256 x 256: the phased kernel
+def test_gemm_f16_lds_epilogue_modes(mode, M, N, K):
+    """The 256 x 256 kernel's LDS epilogue in the four forms the fp16-storage tower uses (round 3 rewrote it: LDS-only
+    barriers, loads of a pass before any store, 8 columns per thread for f16-only results): f16 result + bias (QKV),
+    f16 result + QuickGELU + f16 pre-activation (c_fc), f16 result x QuickGELU'(f16 pre-activation) (d c_proj), fp32
+    result + bias + residual (out / c_proj).  Reference: CPU fp64 on the same f16-rounded operands (NOT a GPU matmul);
+    M = 2088 also runs the leftover-row kernel beside the big one."""
+    from clipfs import ops
+    g = torch.Generator().manual_seed(M + K)
+    a16 = torch.randn(M, K, generator=g).half()
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    w16 = w.half()
+    bias = torch.randn(N, generator=g)
+    ref = a16.double() @ w16.double().T
+    dev = torch.device("cuda:0")
+    wd = w.to(dev)
+    w16d = ops.to_f16(wd)
+    assert torch.equal(w16d.cpu(), w16)
+    kw = dict(b_planes=w16d, a16=a16.to(dev))
+    if mode == "f32_residual":
+        res = torch.randn(M, N, generator=g)
+        out = ops.gemm_nt(None, wd, bias=bias.to(dev), residual=res.to(dev), **kw)
+        want = ref + bias.double() + res.double()
+        assert (out.double().cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        return
+    out16 = torch.empty(M, N, device=dev, dtype=torch.float16)
+    if mode == "f16_bias":
+        ops.gemm_nt(None, wd, None, bias=bias.to(dev), out16=out16, only16=True, **kw)
+        want = ref + bias.double()
+    elif mode == "f16_gelu_aux":
+        aux = torch.empty(M, N, device=dev, dtype=torch.float16)
+        ops.gemm_nt(None, wd, None, bias=bias.to(dev), act=1, aux_out=aux, aux_f16=True, out16=out16, only16=True, **kw)
+        pre = ref + bias.double()
+        want = pre * torch.sigmoid(1.702 * pre)
+        assert (aux.double().cpu() - pre).abs().max().item() <= 1e-3 * pre.abs().max().item()  # one f16 rounding
+    else:
+        u16 = torch.randn(M, N, generator=g).half()
+        ops.gemm_nt(None, wd, None, act=2, aux_in=u16.to(dev), aux_f16=True, out16=out16, only16=True, **kw)
+        sg = torch.sigmoid(1.702 * u16.double())
+        want = ref * (sg * (1 + 1.702 * u16.double() * (1 - sg)))
+    # one rounding to f16 of an fp32-accurate value (2^-11 relative to the element, bounded here by the tensor's scale)
+    assert (out16.double().cpu() - want).abs().max().item() <= 1e-3 * want.abs().max().item()
 
 
 @pytest.mark.gpu
