@@ -34,9 +34,12 @@ for name, M, N, K in shapes:
     e1.record()
     torch.cuda.synchronize()
     ev_us = e0.elapsed_time(e1) * 1e3
-    bm = 64
+    tile_cfg = int(os.environ.get('CLIPFS_GEMM_TILE', '0'))
+    bm, bn = (128, 128) if tile_cfg == 1 else (64, 128)
     S = lib.clipfs_gemm_splits(M, N, K)
-    units = -(-M // bm) * -(-N // 128) * S
+    if tile_cfg == 1:
+        S = 1
+    units = -(-M // bm) * -(-N // bn) * S
     n = min(units, 16384)
     buf = (ctypes.c_ulonglong * (n * 6))()
     assert raw.clipfs_debug_read_stamps(buf, n * 6) == 0
@@ -48,4 +51,4 @@ for name, M, N, K in shapes:
     wall_k = np.median(rt) / 100.0  # us
     print(f"{name:10s} M={M} N={N} K={K} units={units} S={S} event {ev_us:7.1f} us | in-kernel clock {clock:5.3f} GHz | "
           f"prologue {np.median(pro):6.0f} | K loop med {np.median(kl):7.0f} cyc = {wall_k:6.1f} us, min {kl.min():7.0f} "
-          f"({np.median(kl) / (K / 32):5.0f}/K-step) | epilogue med {np.median(ep[ep > 0]):6.0f} | life med {np.median(life):7.0f}")
+          f"({np.median(kl) / (K / 32):5.0f}/K-step; MFMA bound {2 * (bm // 64) * 2048}) | epilogue med {np.median(ep[ep > 0]):6.0f} | life med {np.median(life):7.0f}")
