@@ -184,10 +184,11 @@ int clipfs_attention_f16_fwd(const void* qkv, int qkv_f16, float* out, void* out
 /* dqkv from (qkv, dout, out, lse) of clipfs_attention_f16_fwd; work: batch*heads*seq floats (D_i = dO_i . O_i).
  * out16 / dqkv16 (may be NULL): f16 copies of out / dqkv, the A operands of the GEMMs that follow; with dqkv16 given,
  * dqkv itself may be NULL (fp16 storage mode: every consumer reads the f16 image, see clipfs_lora_bwd_f16dy).
- * qkv_f16 != 0: qkv is an f16 tensor [B*L, 3*d] (the QKV GEMM's f16 output: fp16 storage), else fp32. */
-int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const float* dout, const float* out, const float* lse,
-                             float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads, int causal,
-                             void* stream);
+ * qkv_f16 != 0: qkv is an f16 tensor [B*L, 3*d] (the QKV GEMM's f16 output: fp16 storage), else fp32.
+ * dout_f16 != 0: dout is an f16 tensor [B*L, d] (the output-projection dgrad GEMM's f16-only result), else fp32. */
+int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const void* dout, int dout_f16, const float* out,
+                             const float* lse, float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads,
+                             int causal, void* stream);
 
 /* ------------------------------------------------------------------ LoRA --
  * t[m, s*r + j] = sum_k drop_s(x)[m,k] * A[s*r + j, k]       (the "down" half of

@@ -94,7 +94,7 @@ SIGNATURES = {
     "clipfs_attention_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_attention_lse_floats": (_sz, [_i, _i, _i]),
     "clipfs_attention_f16_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "clipfs_attention_f16_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "clipfs_attention_f16_bwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_lora_down": (_i, [_p, _p, _p, _i, _i, _i, _i, _u, _f, _u64, _u32, _u32, _p]),
     "clipfs_lora_bwd_work_floats": (_sz, [_i, _i, _i, _i]),
     "clipfs_lora_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _u32, _p, _p]),

@@ -185,8 +185,11 @@ def attention_f16_bwd(qkv, dout, out, lse, batch, seq, heads, causal=False):
     f16 = qkv.dtype == torch.float16
     dqkv = torch.empty(qkv.shape, device=qkv.device, dtype=torch.float32)
     work = torch.empty_like(lse)
-    check(_lib.load().clipfs_attention_f16_bwd(_p(qkv if f16 else _f32(qkv)), int(f16), _p(_f32(dout)), _p(out), _p(lse), _p(dqkv), None, _p(work), batch,
-                                               seq, heads, int(causal), _stream()), "attention_f16_bwd")
+    g16 = dout.dtype == torch.float16  # dO as its f16 image (what the fp16-storage tower hands over) or fp32
+    assert dout.is_contiguous()
+    check(_lib.load().clipfs_attention_f16_bwd(_p(qkv if f16 else _f32(qkv)), int(f16), _p(dout if g16 else _f32(dout)), int(g16),
+                                               _p(out), _p(lse), _p(dqkv), None, _p(work), batch, seq, heads, int(causal), _stream()),
+          "attention_f16_bwd")
     return dqkv
 
 

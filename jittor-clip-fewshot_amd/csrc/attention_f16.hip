@@ -205,9 +205,9 @@ __global__ __launch_bounds__(320) void attention_f16_fwd_kernel(const TQ* __rest
 // backward, pass 1: dQ (and D_i = dO_i . O_i for pass 2).  Own side = queries; K (both images) and V in LDS.
 //   S^T = K Q^T ; P^T = exp(S^T c - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - D) / 8 ; dQ^T += K^T dS^T
 // ---------------------------------------------------------------------------------------------------------
-template <typename TQ>
+template <typename TQ, typename TG>
 __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const TQ* __restrict__ qkv,
-                                                                  const float* __restrict__ dout,
+                                                                  const TG* __restrict__ dout,
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                   float* __restrict__ Dbuf, int L, int H, int causal,
@@ -235,15 +235,26 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const TQ* __re
     load_own(q0, ld, qt * 32, L, lane, qf);
     float Di = 0.f;
     {
-      const float* gp = dout + ((size_t)b * L + q_cl) * d + h * AF_HD + 8 * fh;
+      const TG* gp = dout + ((size_t)b * L + q_cl) * d + h * AF_HD + 8 * fh;
       const float* op = out + ((size_t)b * L + q_cl) * d + h * AF_HD + 8 * fh;
 #pragma unroll
       for (int sidx = 0; sidx < 4; ++sidx) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp + 16 * sidx), g1 = *reinterpret_cast<const f32x4*>(gp + 16 * sidx + 4);
+        f32x4 g0, g1;
+        if constexpr (sizeof(TG) == 2) {  // dO given as its f16 image (written by the output-projection dgrad GEMM)
+          gf[sidx] = *reinterpret_cast<const f16x8*>(gp + 16 * sidx);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            g0[j] = (float)gf[sidx][j];
+            g1[j] = (float)gf[sidx][4 + j];
+          }
+        } else {
+          g0 = *reinterpret_cast<const f32x4*>(gp + 16 * sidx);
+          g1 = *reinterpret_cast<const f32x4*>(gp + 16 * sidx + 4);
+          gf[sidx] = cvt8(g0, g1);
+        }
         const f32x4 o0 = *reinterpret_cast<const f32x4*>(op + 16 * sidx), o1 = *reinterpret_cast<const f32x4*>(op + 16 * sidx + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) Di += g0[j] * o0[j] + g1[j] * o1[j];
-        gf[sidx] = cvt8(g0, g1);
       }
       Di += xor32(Di);
     }
@@ -295,9 +306,9 @@ __global__ __launch_bounds__(576) void attention_f16_bwd_q_kernel(const TQ* __re
 //   S = Q K^T ; P = exp(S c - lse) ; dP = dO V^T ; dS = P (dP - D) / 8 ; dV^T += dO^T P ; dK^T += Q^T dS
 // (rows of the MFMA result = queries, so lse and D vary with the register index: read as 4-float groups from LDS).
 // ---------------------------------------------------------------------------------------------------------
-template <typename TQ>
+template <typename TQ, typename TG>
 __global__ __launch_bounds__(576) void attention_f16_bwd_kv_kernel(const TQ* __restrict__ qkv,
-                                                                   const float* __restrict__ dout,
+                                                                   const TG* __restrict__ dout,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ Dbuf,
                                                                    float* __restrict__ dqkv, int L, int H, int causal,
@@ -417,10 +428,6 @@ static void af_set_attrs() {
   if (done) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_fwd_kernel<TQ>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_q_kernel<TQ>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_kv_kernel<TQ>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   done = true;
 }
 
@@ -433,18 +440,26 @@ static int af_fwd(const void* qkv, float* out, void* out16, float* lse, int batc
   return launch_status();
 }
 
-template <typename TQ>
-static int af_bwd(const void* qkv, const float* dout, const float* out, const float* lse, float* dqkv, void* dqkv16,
+template <typename TQ, typename TG>
+static int af_bwd(const void* qkv, const void* dout, const float* out, const float* lse, float* dqkv, void* dqkv16,
                   float* work, int batch, int seq, int heads, int causal, hipStream_t st) {
-  af_set_attrs<TQ>();
   const int threads = af_threads(seq, 9);
-  hipLaunchKernelGGL(attention_f16_bwd_q_kernel<TQ>, dim3(batch * heads), dim3(threads), af_lds_bytes(seq, 2, 1), st,
-                     reinterpret_cast<const TQ*>(qkv), dout, out, lse, dqkv, work, seq, heads, causal,
+  const size_t lds_q = af_lds_bytes(seq, 2, 1);
+  const size_t lds_kv = af_lds_bytes(seq, 2, 2) + 2 * (size_t)((seq + 31) & ~31) * sizeof(float);
+  static bool attr = false;  // per instantiation
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_q_kernel<TQ, TG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16_bwd_kv_kernel<TQ, TG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((attention_f16_bwd_q_kernel<TQ, TG>), dim3(batch * heads), dim3(threads), lds_q, st,
+                     reinterpret_cast<const TQ*>(qkv), reinterpret_cast<const TG*>(dout), out, lse, dqkv, work, seq, heads, causal,
                      reinterpret_cast<_Float16*>(dqkv16));
   CLIPFS_CHECK(launch_status());
-  const size_t lds_kv = af_lds_bytes(seq, 2, 2) + 2 * (size_t)((seq + 31) & ~31) * sizeof(float);
-  hipLaunchKernelGGL(attention_f16_bwd_kv_kernel<TQ>, dim3(batch * heads), dim3(threads), lds_kv, st,
-                     reinterpret_cast<const TQ*>(qkv), dout, lse, work, dqkv, seq, heads, causal,
+  hipLaunchKernelGGL((attention_f16_bwd_kv_kernel<TQ, TG>), dim3(batch * heads), dim3(threads), lds_kv, st,
+                     reinterpret_cast<const TQ*>(qkv), reinterpret_cast<const TG*>(dout), lse, work, dqkv, seq, heads, causal,
                      reinterpret_cast<_Float16*>(dqkv16));
   return launch_status();
 }
@@ -457,13 +472,17 @@ extern "C" int clipfs_attention_f16_fwd(const void* qkv, int qkv_f16, float* out
                  : af_fwd<float>(qkv, out, out16, lse, batch, seq, heads, causal, (hipStream_t)stream);
 }
 
-extern "C" int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const float* dout, const float* out, const float* lse,
-                                        float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads, int causal,
-                                        void* stream) {
+extern "C" int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const void* dout, int dout_f16, const float* out,
+                                        const float* lse, float* dqkv, void* dqkv16, float* work, int batch, int seq, int heads,
+                                        int causal, void* stream) {
   CLIPFS_CHECK(check_af(qkv, dqkv ? (const void*)dqkv : dqkv16, batch, seq, heads));  // the fp32 result is optional beside the f16 one
   CLIPFS_REQUIRE(dout && out && lse && work, "attention_f16_bwd: null pointer");
   CLIPFS_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(out) && aligned16(dqkv) && aligned16(dqkv16),
                  "attention_f16_bwd: misaligned pointer");
-  return qkv_f16 ? af_bwd<_Float16>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, (hipStream_t)stream)
-                 : af_bwd<float>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (dout_f16)
+    return qkv_f16 ? af_bwd<_Float16, _Float16>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, st)
+                   : af_bwd<float, _Float16>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, st);
+  return qkv_f16 ? af_bwd<_Float16, float>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, st)
+                 : af_bwd<float, float>(qkv, dout, out, lse, dqkv, dqkv16, work, batch, seq, heads, causal, st);
 }

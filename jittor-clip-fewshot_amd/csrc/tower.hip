@@ -368,9 +368,12 @@ static int tower_bwd_range(const clipfs_tower* t, float* dx, int batch, const fl
     else
       CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_mid, d, b.ln2_g, sv + SL.stat2, sv + SL.stat2 + M, dx, dx, d, M, d,
                                         st));
-    // attention output projection
+    // attention output projection.  fp16 storage mode without an o-projection adapter: its only consumer is the f16
+    // attention backward, which rounds dO to f16 for its MFMA operands anyway -- the GEMM writes the f16 image alone (into
+    // the same scratch slot): a quarter of the epilogue bytes of an fp32 result, half the bytes the attention kernels stage
+    const bool datt16 = f16_attention(t) && !lora_o && h16 != nullptr;
     CLIPFS_CHECK(gemm(cx, dx, b.w_o_t, b.w_o_t_p, datt, M, d, d, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0.f,
-                      st, CHAIN_NONE, h16));
+                      st, CHAIN_NONE, h16, datt16 ? (void*)datt : nullptr));
     if (lora_o) {
       CLIPFS_REQUIRE(b.g_lora_a_o && b.g_lora_b_o, "tower_bwd: block %d o-LoRA gradient slots missing", l);
       CLIPFS_CHECK(clipfs_lora_bwd(dx, sv + SL.att, sv + SL.t_o, b.lora_a_o, b.lora_b_o, dt, b.g_lora_a_o, b.g_lora_b_o,
@@ -382,8 +385,8 @@ static int tower_bwd_range(const clipfs_tower* t, float* dx, int batch, const fl
     // attention backward does not write the fp32 tensor at all (404 MB per ViT-L/14 block at 128 images)
     const bool dy16 = f16_attention(t) && dqkv16 && (!qkv_mask || clipfs_lora_bwd_f16dy_ok(d, d, r, 3));
     if (f16_attention(t)) {
-      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dy16 ? nullptr : dqkv, dqkv16,
-                                            dh, batch, t->seq, t->heads, t->causal, st));
+      CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, datt16 ? 1 : 0, sv + SL.att, sv + SL.lse,
+                                            dy16 ? nullptr : dqkv, dqkv16, dh, batch, t->seq, t->heads, t->causal, st));
       dqkv16_ready = dqkv16;
     } else
       CLIPFS_CHECK(clipfs_attention_bwd(sv + SL.qkv, datt, sv + SL.att, sv + SL.lse, dqkv, dh, batch, t->seq, t->heads,
@@ -485,7 +488,7 @@ extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, 
   void* dqkv16 = (f16_attention(t) && cx.a16) ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
   const bool dy16 = dqkv16 && (!qkv_mask || clipfs_lora_bwd_f16dy_ok(d, d, r, 3));  // as in tower_bwd_range
   if (f16_attention(t)) {
-    CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, sv + SL.att, sv + SL.lse, dy16 ? nullptr : dqkv, dqkv16,
+    CLIPFS_CHECK(clipfs_attention_f16_bwd(sv + SL.qkv, qkv_f16(t), datt, 0, sv + SL.att, sv + SL.lse, dy16 ? nullptr : dqkv, dqkv16,
                                           dh, batch, seq, t->heads, t->causal, st));
     dqkv16_ready = dqkv16;
   } else

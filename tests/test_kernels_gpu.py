@@ -622,6 +622,10 @@ def test_attention_f16_bwd(batch, seq, heads, causal):
     out, lse = ops.attention_f16_fwd(qkv, batch, seq, heads, causal)
     dqkv = ops.attention_f16_bwd(qkv, dout, out, lse, batch, seq, heads, causal)
     assert torch.equal(ops.attention_f16_bwd(qkv.half(), dout, out, lse, batch, seq, heads, causal), dqkv)
+    # dO handed over as its f16 image (fp16 storage mode: the output-projection dgrad writes nothing else): same bits,
+    # with either storage of qkv -- dout above is f16-representable and the fp32 staging rounds it the same way
+    assert torch.equal(ops.attention_f16_bwd(qkv, dout.half(), out, lse, batch, seq, heads, causal), dqkv)
+    assert torch.equal(ops.attention_f16_bwd(qkv.half(), dout.half(), out, lse, batch, seq, heads, causal), dqkv)
     x = qkv.double().requires_grad_(True)
     ro, _ = _attn_ref64(x, batch, seq, heads, causal)
     (ro * dout.double()).sum().backward()
