@@ -383,6 +383,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0  # host time to enqueue the K steps (== dt when the host, not the GPU, is the limit)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -513,6 +514,7 @@ def main():
             "metric": "images/sec ViT-B/32 fwd+LoRA-bwd bs=256" if args.model == "b32" else
                       "images/sec ViT-L/14 fwd+LoRA-bwd (cfg-5 shapes)", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (tower GEMMs as split-bf16 x3 MFMA, fp32 accumulate)", "fp16": "f16 operands in the tower GEMMs, fp32 accumulate"}[args.precision], "data": "synthetic",
             "config": {"workload": ("ViT-B/32 image tower forward only (diagnostic)" if args.forward_only else

@@ -186,11 +186,10 @@ __global__ __launch_bounds__(64) void lora_da_partial_kernel(const float* __rest
 
 // out[i] += scale * sum_slice part[slice][i].  64 outputs x 16 slice groups per block; group g sums slices
 // g, g+16, ... and the 16 group sums are added in a fixed order => bitwise reproducible.
-__global__ __launch_bounds__(1024) void reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                             size_t n, int slices, float scale) {
-  __shared__ float red[16][64];
+__device__ __forceinline__ void reduce_slices_body(const float* __restrict__ part, float* __restrict__ out, size_t n,
+                                                   int slices, float scale, unsigned block, float (*red)[64]) {
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  const size_t i = (size_t)block * 64 + lane;
   float acc = 0.f;
   if (i < n)
     for (int s = grp; s < slices; s += 16) acc += part[(size_t)s * n + i];
@@ -202,6 +201,23 @@ __global__ __launch_bounds__(1024) void reduce_slices_kernel(const float* __rest
     for (int g = 0; g < 16; ++g) t += red[g][lane];
     out[i] += scale * t;
   }
+}
+
+__global__ __launch_bounds__(1024) void reduce_slices_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                             size_t n, int slices, float scale) {
+  __shared__ float red[16][64];
+  reduce_slices_body(part, out, n, slices, scale, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(1024) void reduce_slices2_kernel(const float* __restrict__ part0, float* __restrict__ out0,
+                                                              size_t n0, int slices0, float scale0,
+                                                              const float* __restrict__ part1, float* __restrict__ out1,
+                                                              size_t n1, int slices1, float scale1, unsigned nblk0) {
+  __shared__ float red[16][64];
+  if (blockIdx.x < nblk0)
+    reduce_slices_body(part0, out0, n0, slices0, scale0, blockIdx.x, red);
+  else
+    reduce_slices_body(part1, out1, n1, slices1, scale1, blockIdx.x - nblk0, red);
 }
 
 // dx[m,k] += sum_{s,j} dt[m, s*r+j] * A[s*r+j, k] * dropscale_s(m,k)       one wave per row
@@ -259,17 +275,22 @@ static inline int lora_slice_rows(int rows) {
 bool lora_mfma_ok(int width, int segw, int r, int nseg);
 int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
                    float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, hipStream_t st);
+typedef void (*lora_reduce2_fn)(const float*, float*, size_t, int, float, const float*, float*, size_t, int, float, hipStream_t);
 int lora_bwd_mfma_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                         float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
                         float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                        void (*reduce)(const float*, float*, size_t, int, float, hipStream_t));
+                        lora_reduce2_fn reduce);
 int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                   float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                  void (*reduce)(const float*, float*, size_t, int, float, hipStream_t));
+                  lora_reduce2_fn reduce);
 
-static void launch_reduce_slices(const float* part, float* out, size_t n, int slices, float scale, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_slices_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, part, out, n, slices, scale);
+// the dB and dA slice sums of one adapter backward in one launch (blocks [0, nblk0) take the first)
+static void launch_reduce_slices2(const float* part0, float* out0, size_t n0, int slices0, float scale0, const float* part1,
+                                  float* out1, size_t n1, int slices1, float scale1, hipStream_t st) {
+  const unsigned nblk0 = (unsigned)((n0 + 63) / 64), nblk1 = (unsigned)((n1 + 63) / 64);
+  hipLaunchKernelGGL(reduce_slices2_kernel, dim3(nblk0 + nblk1), dim3(1024), 0, st, part0, out0, n0, slices0, scale0, part1,
+                     out1, n1, slices1, scale1, nblk0);
 }
 
 static bool use_lora_mfma() {
@@ -362,7 +383,7 @@ extern "C" int clipfs_lora_bwd(const float* dy, const float* x, const float* t, 
   hipStream_t st = (hipStream_t)stream;
   if (use_lora_mfma() && lora_mfma_ok(width, segw, r, nseg) && aligned16(dy) && aligned16(dx ? dx : x))
     return lora_bwd_mfma(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base, drow0,
-                         work, st, launch_reduce_slices);
+                         work, st, launch_reduce_slices2);
 #define CLIPFS_LORA_CASE(RR)                                                                                       \
   case RR:                                                                                                         \
     return lora_bwd_r<RR>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, nseg, seg_mask, scale, p, seed,       \
@@ -398,5 +419,5 @@ extern "C" int clipfs_lora_bwd_f16dy(const void* dy16, const float* x, const flo
   CLIPFS_REQUIRE(aligned16(dy16) && aligned16(x) && aligned16(A) && aligned16(work) && (!dx || aligned16(dx)),
                  "lora_bwd_f16dy: misaligned pointer");
   return lora_bwd_mfma_f16dy(dy16, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base,
-                             drow0, work, (hipStream_t)stream, launch_reduce_slices);
+                             drow0, work, (hipStream_t)stream, launch_reduce_slices2);
 }

@@ -122,15 +122,14 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __rest
   }
 }
 
-// dt = scale * dy_seg B_seg
+// dt = scale * dy_seg B_seg.  One block (index bx) per 16 rows.
 template <int NSEG, typename TY>
-__global__ __launch_bounds__(256) void lora_dt_mfma_kernel(const TY* __restrict__ dy, const float* __restrict__ B,
-                                                           float* __restrict__ dt, int rows, int segw, int r,
-                                                           unsigned seg_mask, float scale) {
-  __shared__ f32x4 red[3 * NSEG * 64];
+__device__ __forceinline__ void lora_dt_mfma_body(const TY* __restrict__ dy, const float* __restrict__ B,
+                                                  float* __restrict__ dt, int rows, int segw, int r, unsigned seg_mask,
+                                                  float scale, int bx, f32x4* red) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = bx * 16;
   const int m = min(row0 + li, rows - 1);
   const int cw = segw >> 2;
   const TY* dr = dy + (size_t)m * NSEG * segw + 4 * kg;
@@ -177,13 +176,13 @@ __global__ __launch_bounds__(256) void lora_dt_mfma_kernel(const TY* __restrict_
 // dB partials: part[slice][n][j] = sum_{m in slice} dy[m, n] t[m, seg(n) r + j].  One wave per (64 columns, slice);
 // lane i owns columns n0 + 4 i + e of MFMA tile e.
 template <typename TY>
-__global__ __launch_bounds__(256) void lora_db_mfma_kernel(const TY* __restrict__ dy, const float* __restrict__ t,
-                                                           float* __restrict__ part, int rows, int cols, int segw,
-                                                           int nseg, int r, int rows_per_slice) {
+__device__ __forceinline__ void lora_db_mfma_body(const TY* __restrict__ dy, const float* __restrict__ t,
+                                                  float* __restrict__ part, int rows, int cols, int segw, int nseg, int r,
+                                                  int rows_per_slice, int bx, int by) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int n0 = (bx * 4 + (threadIdx.x >> 6)) * 64;
   if (n0 >= cols) return;
-  const int slice = blockIdx.y;
+  const int slice = by;
   const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
   const int s = n0 / segw;
   const int tw = nseg * r;
@@ -224,14 +223,14 @@ __global__ __launch_bounds__(256) void lora_db_mfma_kernel(const TY* __restrict_
 // dA partials: part[slice][s r + j][k] = sum_{m in slice} dt[m, s r + j] drop_s(x)[m, k].  One wave per (64 columns,
 // slice); lane i owns columns k0 + 4 i + e of MFMA tile e (so one Philox call covers the lane's float4 of x).
 template <int NSEG>
-__global__ __launch_bounds__(256) void lora_da_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dt,
-                                                           float* __restrict__ part, int rows, int width, int r,
-                                                           unsigned seg_mask, float p, uint64_t seed,
-                                                           uint32_t stream_base, uint32_t drow0, int rows_per_slice) {
+__device__ __forceinline__ void lora_da_mfma_body(const float* __restrict__ x, const float* __restrict__ dt,
+                                                  float* __restrict__ part, int rows, int width, int r, unsigned seg_mask,
+                                                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
+                                                  int rows_per_slice, int bx, int by) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
-  const int k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int k0 = (bx * 4 + (threadIdx.x >> 6)) * 64;
   if (k0 >= width) return;
-  const int slice = blockIdx.y;
+  const int slice = by;
   const int m0 = slice * rows_per_slice, m1 = min(rows, m0 + rows_per_slice);
   const bool drop = p > 0.f && seed != 0;
   const uint32_t thr = dropout_threshold(p);
@@ -295,13 +294,12 @@ __global__ __launch_bounds__(256) void lora_da_mfma_kernel(const float* __restri
 // quarter of the columns each); per 16-column tile
 // the result D[i <-> column k0 + i][j <-> row] gives a lane 4 consecutive columns of one row: a float4 of dx.
 template <int NSEG, int RQ>  // RQ = ceil(r / 4) MFMA K-steps
-__global__ __launch_bounds__(256) void lora_dx_mfma_kernel(const float* __restrict__ dt, const float* __restrict__ A,
-                                                           float* __restrict__ dx, int rows, int width, int r,
-                                                           unsigned seg_mask, float p, uint64_t seed,
-                                                           uint32_t stream_base, uint32_t drow0) {
+__device__ __forceinline__ void lora_dx_mfma_body(const float* __restrict__ dt, const float* __restrict__ A,
+                                                  float* __restrict__ dx, int rows, int width, int r, unsigned seg_mask,
+                                                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, int bx) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = bx * 16;
   const int m = row0 + li;
   const int mc = min(m, rows - 1);
   const int cw = width >> 2;
@@ -355,6 +353,40 @@ __global__ __launch_bounds__(256) void lora_dx_mfma_kernel(const float* __restri
   }
 }
 
+// ---- the backward as three launches ---------------------------------------------------------------------------
+// dt and dB both read dy and do not depend on each other; dA and dx both need dt and touch different tensors.  Each
+// pair is ONE launch whose leading blocks do the first product and whose trailing blocks do the second (the bodies
+// above, unchanged: same arithmetic, same results): at the per-rank sizes of the 8-GPU step every one of these products
+// is a few microseconds of work behind ~10 us of launch, and the two halves of a pair fill each other's tail.
+template <int NSEG, typename TY>
+__global__ __launch_bounds__(256) void lora_db_dt_mfma_kernel(const TY* __restrict__ dy, const float* __restrict__ B,
+                                                              const float* __restrict__ t, float* __restrict__ dt,
+                                                              float* __restrict__ part_b, int rows, int segw, int r,
+                                                              unsigned seg_mask, float scale, int rows_per_slice,
+                                                              int gx_b, int n_db) {
+  __shared__ f32x4 red[3 * NSEG * 64];
+  const int b = blockIdx.x;
+  if (b < n_db)
+    lora_db_mfma_body<TY>(dy, t, part_b, rows, NSEG * segw, segw, NSEG, r, rows_per_slice, b % gx_b, b / gx_b);
+  else
+    lora_dt_mfma_body<NSEG, TY>(dy, B, dt, rows, segw, r, seg_mask, scale, b - n_db, red);
+}
+
+template <int NSEG, int RQ>
+__global__ __launch_bounds__(256) void lora_da_dx_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dt,
+                                                              const float* __restrict__ A, float* __restrict__ part_a,
+                                                              float* __restrict__ dx, int rows, int width, int r,
+                                                              unsigned seg_mask, float p, uint64_t seed,
+                                                              uint32_t stream_base, uint32_t drow0, int rows_per_slice,
+                                                              int gx_a, int n_da) {
+  const int b = blockIdx.x;
+  if (b < n_da)
+    lora_da_mfma_body<NSEG>(x, dt, part_a, rows, width, r, seg_mask, p, seed, stream_base, drow0, rows_per_slice, b % gx_a,
+                            b / gx_a);
+  else
+    lora_dx_mfma_body<NSEG, RQ>(dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, b - n_da);
+}
+
 // ---- host side (called from lora.hip) ---------------------------------------------------------------------
 
 bool lora_mfma_ok(int width, int segw, int r, int nseg) {
@@ -379,55 +411,61 @@ int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width
   return launch_status();
 }
 
+template <int NSEG, int RQ>
+static void launch_da_dx(const float* x, const float* dt, const float* A, float* part_a, float* dx, int rows, int width, int r,
+                         unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, int sr_a, int slices_a,
+                         hipStream_t st) {
+  const int gx_a = (width + 255) / 256, n_da = gx_a * slices_a;
+  const int n_dx = dx ? (rows + 15) / 16 : 0;
+  hipLaunchKernelGGL((lora_da_dx_mfma_kernel<NSEG, RQ>), dim3(n_da + n_dx), dim3(256), 0, st, x, dt, A, part_a, dx, rows, width,
+                     r, seg_mask, p, seed, stream_base, drow0, sr_a, gx_a, n_da);
+}
+
+// reduce2(part_b, dB, nb, slices_b, scale_b, part_a, dA, na, slices_a, scale_a): both slice sums in one launch
+typedef void (*lora_reduce2_fn)(const float*, float*, size_t, int, float, const float*, float*, size_t, int, float, hipStream_t);
+
 template <int NSEG, typename TY>
 static int lora_bwd_mfma_n(const TY* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
                            float* dA, float* dB, float* dx, int rows, int width, int segw, int r, unsigned seg_mask,
                            float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                           void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
+                           lora_reduce2_fn reduce2) {
   const int cols = NSEG * segw;
   const int sr_b = lora_mfma_slice_rows(rows, cols / 64), slices_b = (rows + sr_b - 1) / sr_b;
   const int sr_a = lora_mfma_slice_rows(rows, width / 64), slices_a = (rows + sr_a - 1) / sr_a;
-  const dim3 rgrid((rows + 15) / 16);
-  hipLaunchKernelGGL((lora_dt_mfma_kernel<NSEG, TY>), rgrid, dim3(256), 0, st, dy, B, dt, rows, segw, r, seg_mask, scale);
-  CLIPFS_CHECK(launch_status());
+  const int n_rows16 = (rows + 15) / 16;
+  const size_t nb = (size_t)cols * r, na = (size_t)NSEG * r * width;
   float* part_b = work;
-  hipLaunchKernelGGL(lora_db_mfma_kernel<TY>, dim3((cols + 255) / 256, slices_b), dim3(256), 0, st, dy, t, part_b, rows, cols,
-                     segw, NSEG, r, sr_b);
-  CLIPFS_CHECK(launch_status());
-  const size_t nb = (size_t)cols * r;
-  reduce(part_b, dB, nb, slices_b, scale, st);
-  CLIPFS_CHECK(launch_status());
   float* part_a = work + (((size_t)slices_b * nb + 3) & ~(size_t)3);
-  hipLaunchKernelGGL((lora_da_mfma_kernel<NSEG>), dim3((width + 255) / 256, slices_a), dim3(256), 0, st, x, dt, part_a, rows,
-                     width, r, seg_mask, p, seed, stream_base, drow0, sr_a);
+  // 1: dB partials || dt
+  const int gx_b = (cols + 255) / 256, n_db = gx_b * slices_b;
+  hipLaunchKernelGGL((lora_db_dt_mfma_kernel<NSEG, TY>), dim3(n_db + n_rows16), dim3(256), 0, st, dy, B, t, dt, part_b, rows,
+                     segw, r, seg_mask, scale, sr_b, gx_b, n_db);
   CLIPFS_CHECK(launch_status());
-  const size_t na = (size_t)NSEG * r * width;
-  reduce(part_a, dA, na, slices_a, 1.0f, st);
-  CLIPFS_CHECK(launch_status());
-  if (dx) {
-    switch ((r + 3) / 4) {
-      case 1:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 1>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
-        break;
-      case 2:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 2>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
-        break;
-      case 3:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 3>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
-        break;
-      default:
-        hipLaunchKernelGGL((lora_dx_mfma_kernel<NSEG, 4>), rgrid, dim3(256), 0, st, dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0);
-        break;
-    }
-    CLIPFS_CHECK(launch_status());
+  // 2: dA partials || dx
+  switch ((r + 3) / 4) {
+    case 1:
+      launch_da_dx<NSEG, 1>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      break;
+    case 2:
+      launch_da_dx<NSEG, 2>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      break;
+    case 3:
+      launch_da_dx<NSEG, 3>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      break;
+    default:
+      launch_da_dx<NSEG, 4>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      break;
   }
-  return CLIPFS_OK;
+  CLIPFS_CHECK(launch_status());
+  // 3: both slice sums
+  reduce2(part_b, dB, nb, slices_b, scale, part_a, dA, na, slices_a, 1.0f, st);
+  return launch_status();
 }
 
 int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                   float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                  void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
+                  lora_reduce2_fn reduce) {
   if (nseg == 1)
     return lora_bwd_mfma_n<1, float>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
                                      work, st, reduce);
@@ -439,7 +477,7 @@ int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* 
 int lora_bwd_mfma_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                         float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
                         float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                        void (*reduce)(const float*, float*, size_t, int, float, hipStream_t)) {
+                        lora_reduce2_fn reduce) {
   const _Float16* dy = reinterpret_cast<const _Float16*>(dy16);
   if (nseg == 1)
     return lora_bwd_mfma_n<1, _Float16>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
