@@ -157,6 +157,17 @@ int clipfs_layernorm_fwd_f16(const float* x, int ldx, const float* gamma, const 
 int clipfs_layernorm_bwd_f16(const float* dy, const float* x, int ldx, const float* gamma, const float* mean,
                              const float* rstd, const float* dres, float* dx, void* dx16, int lddx, int rows, int width,
                              void* stream);
+/* LayerNorm forward with the adapter's down-projection in the same pass: y = LN(x) (and / or its f16 copy y16) and
+ * t[row, s*r + j] = sum_k dropout_s(y)[row, k] * A[s*r + j, k], exactly clipfs_layernorm_fwd(_f16) followed by
+ * clipfs_lora_down on y (same Philox counters, so clipfs_lora_bwd regenerates the same masks; t agrees to fp32 summation
+ * order).  Replaces ln_1 + lora_A(dropout(x)) of the adapted q/k/v projections, jclip/model.py:115 with
+ * lora_train_vlp.py:296-306.  Covered: nseg == 3, r in {1, 2, 4} (clipfs_layernorm_fwd_lora_ok); other shapes take the
+ * two separate calls. */
+int clipfs_layernorm_fwd_lora_ok(int width, int r, int nseg);
+int clipfs_layernorm_fwd_lora(const float* x, int ldx, const float* gamma, const float* beta, float* y, void* y16,
+                              float* mean, float* rstd, int rows, int width, float eps, const float* A, float* t, int r,
+                              int nseg, unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
+                              void* stream);
 
 /* ------------------------------------------------------------- attention --
  * qkv [B*L, 3*d] (q | k | v, head h at columns h*64..), out [B*L, d] heads merged.

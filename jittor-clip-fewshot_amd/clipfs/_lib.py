@@ -89,6 +89,8 @@ SIGNATURES = {
     "clipfs_layernorm_fwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "clipfs_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_layernorm_fwd_f16": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "clipfs_layernorm_fwd_lora_ok": (_i, [_i, _i, _i]),
+    "clipfs_layernorm_fwd_lora": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _i, _i, _u, _f, _u64, _u32, _u32, _p]),
     "clipfs_layernorm_bwd_f16": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_attention_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -149,6 +149,25 @@ def layernorm_fwd(x, gamma, beta, *, ldx=None, rows=None, save_stats=False, eps=
     return (y, mean, rstd) if save_stats else y
 
 
+def layernorm_fwd_lora(x, gamma, beta, A, r, nseg=3, *, seg_mask=None, p=0.0, seed=0, stream_base=0, row0=0, eps=1e-5):
+    """LayerNorm + adapter down-projection in one pass: returns (y, t, mean, rstd)."""
+    width = gamma.numel()
+    rows = x.numel() // width
+    lib = _lib.load()
+    if not lib.clipfs_layernorm_fwd_lora_ok(width, r, nseg):
+        raise ValueError(f"layernorm_fwd_lora: width {width} r {r} nseg {nseg} is not covered")
+    y = torch.empty(rows, width, device=x.device, dtype=torch.float32)
+    t = torch.empty(rows, nseg * r, device=x.device, dtype=torch.float32)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    if seg_mask is None:
+        seg_mask = (1 << nseg) - 1
+    check(lib.clipfs_layernorm_fwd_lora(_p(_f32(x)), width, _p(gamma), _p(beta), _p(y), None, _p(mean), _p(rstd), rows, width,
+                                        eps, _p(_f32(A)), _p(t), r, nseg, seg_mask, p, seed, stream_base, row0, _stream()),
+          "layernorm_fwd_lora")
+    return y, t, mean, rstd
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, *, ldx=None, dres=None, dx=None, lddx=None):
     width = gamma.numel()
     rows = dy.numel() // width

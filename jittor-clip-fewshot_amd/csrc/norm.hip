@@ -3,6 +3,8 @@
 // fwd 2*width*4 (+8 for mean/rstd), bwd 3..4*width*4.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace clipfs {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -59,6 +61,103 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, int 
       if (yh) yh[c] = f16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
     }
   }
+  if (mean_out && lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+// LayerNorm forward with the adapter's down-projection in the same pass (ranks up to 4 on q, k, v: cfg-2 / cfg-3):
+//   y = LN(x) ;  t[row, s r + j] = sum_k drop_s(y)[row, k] A[s r + j, k]      (lora_train_vlp.py:296-306: lora_A(dropout(x)))
+// The normalised row is in the wave's registers when it is stored, so the separate clipfs_lora_down launch (a second
+// read of y plus, at the per-rank sizes of the 8-GPU step, ~10 us of launch for ~2 us of work) is folded in: per float4
+// of y one Philox call per adapted segment (the same (stream, row, column group) counter as the stand-alone kernel, so
+// the backward's masks agree), NSEG * R dot products against A (12 rows of <= 8 KiB: cache resident), NSEG * R wave sums.
+template <int NSEG, int R>
+__global__ __launch_bounds__(256) void layernorm_fwd_lora_kernel(const float* x, int ldx, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* y,
+                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                 int rows, int width, float eps, _Float16* __restrict__ y16,
+                                                                 const float* __restrict__ A, float* __restrict__ t,
+                                                                 unsigned seg_mask, float p, uint64_t seed,
+                                                                 uint32_t stream_base, uint32_t drow0) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = width >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+  float4 v[LN_MAX_CHUNKS];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      v[i] = xr[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)width;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)width + eps);
+  float4* yr = y ? reinterpret_cast<float4*>(y + (size_t)row * width) : nullptr;
+  f16x4* yh = y16 ? reinterpret_cast<f16x4*>(y16 + (size_t)row * width) : nullptr;
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  const float4* A4 = reinterpret_cast<const float4*>(A);
+  const bool drop = p > 0.f && seed != 0;
+  const uint32_t thr = dropout_threshold(p);
+  const float inv_keep = 1.f / (1.f - p);
+  float acc[NSEG][R];
+#pragma unroll
+  for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[sg][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 g = g4[c], b = b4[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + b.x;
+      o.y = (v[i].y - mean) * rstd * g.y + b.y;
+      o.z = (v[i].z - mean) * rstd * g.z + b.z;
+      o.w = (v[i].w - mean) * rstd * g.w + b.w;
+      if (yr) yr[c] = o;
+      if (yh) yh[c] = f16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+#pragma unroll
+      for (int sg = 0; sg < NSEG; ++sg) {
+        if (!((seg_mask >> sg) & 1u)) continue;
+        float4 xs = o;
+        if (drop) {
+          const float4 mk = dropout_scale4(seed, stream_base + sg, drow0 + (uint32_t)row, (uint32_t)c, thr, inv_keep);
+          xs.x *= mk.x;
+          xs.y *= mk.y;
+          xs.z *= mk.z;
+          xs.w *= mk.w;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const float4 a = A4[(size_t)(sg * R + j) * nch + c];
+          acc[sg][j] = fmaf(xs.w, a.w, fmaf(xs.z, a.z, fmaf(xs.y, a.y, fmaf(xs.x, a.x, acc[sg][j]))));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int sg = 0; sg < NSEG; ++sg)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const float tot = wave_sum(acc[sg][j]);
+      if (lane == 0) t[(size_t)row * (NSEG * R) + sg * R + j] = tot;  // segments outside seg_mask: 0
+    }
   if (mean_out && lane == 0) {
     mean_out[row] = mean;
     rstd_out[row] = rstd;
@@ -257,5 +356,42 @@ extern "C" int clipfs_layernorm_bwd_f16(const float* dy, const float* x, int ldx
                  "layernorm_bwd_f16: alignment");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, ldx, gamma,
                      mean, rstd, dres, dx, lddx, rows, width, reinterpret_cast<_Float16*>(dx16));
+  return launch_status();
+}
+
+// LayerNorm + adapter down-projection in one pass; covered shapes: 3 segments (q, k, v), rank 1, 2 or 4
+extern "C" int clipfs_layernorm_fwd_lora_ok(int width, int r, int nseg) {
+  static const int cfg = getenv("CLIPFS_LN_LORA") ? atoi(getenv("CLIPFS_LN_LORA")) : 1;  // 0: separate launches (A/B aid)
+  return (cfg != 0 && nseg == 3 && (r == 1 || r == 2 || r == 4) && width > 0 && (width & 3) == 0 && width <= 256 * LN_MAX_CHUNKS) ? 1 : 0;
+}
+
+extern "C" int clipfs_layernorm_fwd_lora(const float* x, int ldx, const float* gamma, const float* beta, float* y, void* y16,
+                                         float* mean, float* rstd, int rows, int width, float eps, const float* A, float* t,
+                                         int r, int nseg, unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base,
+                                         uint32_t drow0, void* stream) {
+  CLIPFS_CHECK(check_rows("layernorm_fwd_lora", rows, width));
+  CLIPFS_REQUIRE(x && gamma && beta && (y || y16) && A && t, "layernorm_fwd_lora: null pointer");
+  CLIPFS_REQUIRE((mean == nullptr) == (rstd == nullptr), "layernorm_fwd_lora: mean and rstd must both be given or both NULL");
+  CLIPFS_REQUIRE(clipfs_layernorm_fwd_lora_ok(width, r, nseg), "layernorm_fwd_lora: width %d r %d nseg %d is not covered", width, r, nseg);
+  CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "layernorm_fwd_lora: dropout p %f out of range", (double)p);
+  CLIPFS_REQUIRE(ldx >= width && (ldx & 3) == 0 && aligned16(x) && (!y || aligned16(y)) && (!y16 || aligned16(y16)) &&
+                     aligned16(gamma) && aligned16(beta) && aligned16(A), "layernorm_fwd_lora: alignment");
+  const dim3 grid((rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  _Float16* h = reinterpret_cast<_Float16*>(y16);
+  switch (r) {
+    case 1:
+      hipLaunchKernelGGL((layernorm_fwd_lora_kernel<3, 1>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, rows, width,
+                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0);
+      break;
+    case 2:
+      hipLaunchKernelGGL((layernorm_fwd_lora_kernel<3, 2>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, rows, width,
+                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0);
+      break;
+    default:
+      hipLaunchKernelGGL((layernorm_fwd_lora_kernel<3, 4>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, rows, width,
+                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0);
+      break;
+  }
   return launch_status();
 }

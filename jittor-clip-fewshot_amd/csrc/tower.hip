@@ -239,14 +239,21 @@ static int tower_fwd_impl(const clipfs_tower* t, float* x, const int32_t* rows, 
     void* h16 = cx.a16;                                                        // [M, d] halves: ln1 / attention / ln2 / dx
     void* dqkv16 = cx.a16 ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
     (void)dqkv16;
-    if (h16)
-      CLIPFS_CHECK(clipfs_layernorm_fwd_f16(x_in, d, b.ln1_g, b.ln1_b, h1, h16, train ? sv + SL.stat1 : nullptr,
-                                            train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
-    else
-      CLIPFS_CHECK(clipfs_layernorm_fwd(x_in, d, b.ln1_g, b.ln1_b, h1, train ? sv + SL.stat1 : nullptr,
-                                        train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
-    if (qkv_mask)
-      CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, t->dropout_row0, st));
+    if (qkv_mask && clipfs_layernorm_fwd_lora_ok(d, r, 3)) {
+      // small ranks: the adapter's down-projection rides on the LayerNorm pass (the row is in registers there)
+      CLIPFS_CHECK(clipfs_layernorm_fwd_lora(x_in, d, b.ln1_g, b.ln1_b, h1, h16, train ? sv + SL.stat1 : nullptr,
+                                             train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, b.lora_a_qkv, t_qkv, r, 3, qkv_mask,
+                                             t->lora_dropout, seed, ds, t->dropout_row0, st));
+    } else {
+      if (h16)
+        CLIPFS_CHECK(clipfs_layernorm_fwd_f16(x_in, d, b.ln1_g, b.ln1_b, h1, h16, train ? sv + SL.stat1 : nullptr,
+                                              train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
+      else
+        CLIPFS_CHECK(clipfs_layernorm_fwd(x_in, d, b.ln1_g, b.ln1_b, h1, train ? sv + SL.stat1 : nullptr,
+                                          train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
+      if (qkv_mask)
+        CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, t->dropout_row0, st));
+    }
     const bool q16 = qkv_f16(t);
     CLIPFS_CHECK(gemm(cx, h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
                       b.lora_b_qkv, r, 3, d, t->lora_scale, st, CHAIN_NONE, h16, q16 ? (void*)qkv : nullptr));

@@ -195,6 +195,44 @@ def test_lora_down_and_bwd(dev, p, rows, width, r, nseg):
     _close(dx, xs.grad, 2e-4, "lora dx")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("rows,width,r,mask", [(333, 768, 4, 7), (1601, 512, 4, 5), (50, 1024, 2, 7), (7, 192, 1, 2)])
+def test_layernorm_with_lora_down(dev, p, rows, width, r, mask):
+    """LayerNorm + adapter down-projection in one pass (clipfs_layernorm_fwd_lora, the small-rank path of the tower) against
+    an fp64 restatement with the oracle's Philox masks: y and the statistics are the plain LayerNorm's bits, t is the
+    down-projection of dropout(y) to fp32 rounding (2e-5 of the largest entry); segments outside the mask are zero."""
+    from clipfs import ops
+    from oracle import clip_oracle as O
+    seed, sb, row0 = 0x5EED1234, 11, 40
+    x = _rand(rows, width, seed=5, scale=2.0) + 0.3
+    g = _rand(width, seed=6) * 0.1 + 1.0
+    b = _rand(width, seed=7) * 0.1
+    A = _rand(3 * r, width, seed=8, scale=width ** -0.5)
+    D = lambda t: t.detach().float().to(dev)
+    y, t, mean, rstd = ops.layernorm_fwd_lora(D(x), D(g), D(b), D(A), r, 3, seg_mask=mask, p=p, seed=seed if p > 0 else 0,
+                                              stream_base=sb, row0=row0)
+    y0, m0, r0 = ops.layernorm_fwd(D(x), D(g), D(b), save_stats=True)
+    assert torch.equal(y, y0) and torch.equal(mean, m0) and torch.equal(rstd, r0)
+    yd = y.double().cpu()
+    ref = torch.zeros(rows, 3 * r, dtype=torch.float64)
+    for s in range(3):
+        if not (mask >> s) & 1:
+            continue
+        m = torch.ones(rows, width, dtype=torch.float64)
+        if p > 0:
+            keep = O.dropout_keep_mask(seed, sb + s, rows + row0, width, p)[row0:]
+            m = torch.from_numpy(keep).double() / (1 - p)
+        ref[:, s * r:(s + 1) * r] = (yd * m) @ A[s * r:(s + 1) * r].double().t()
+    _close(t, ref, 2e-5, "fused lora down")
+    for s in range(3):
+        if not (mask >> s) & 1:
+            assert t[:, s * r:(s + 1) * r].abs().max().item() == 0.0
+    # and the stand-alone kernel on the same y (what the backward's masks were tested against)
+    t1 = ops.lora_down(y, D(A), r, 3, seg_mask=mask, p=p, seed=seed if p > 0 else 0, stream_base=sb, row0=row0)
+    _close(t, t1.double().cpu(), 2e-5, "fused vs stand-alone down")
+
+
 def test_dropout_rate(dev):
     """Philox keep-rate of the device stream is 1 - p (statistical sanity, 1e6 draws)."""
     from clipfs import ops
