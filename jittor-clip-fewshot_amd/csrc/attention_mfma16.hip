@@ -201,14 +201,12 @@ __global__ __launch_bounds__(64 * NT) void attention16_fwd_kernel(const float* _
 }
 
 // dQ pass (own = 16 queries).  S^T = K Q^T ; P^T = exp2(S^T c - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - D) / 8 ;
-// dQ^T = K^T dS^T.  Also writes D_i = dO_i . O_i for the dK/dV pass.
+// dQ^T = K^T dS^T.  D_i = dO_i . O_i from the own rows in registers.
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void attention16_bwd_q_kernel(const float* __restrict__ qkv,
-                                                                    const float* __restrict__ dout,
-                                                                    const float* __restrict__ out,
-                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
-                                                                    float* __restrict__ Dbuf, int L, int H, int causal) {
-  extern __shared__ __attribute__((aligned(16))) float a16_smem[];
+__device__ __forceinline__ void attention16_bwd_q_body(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                       const float* __restrict__ out, const float* __restrict__ lse,
+                                                       float* __restrict__ dqkv, int L, int H, int causal, int item,
+                                                       float* a16_smem) {
   constexpr int TP = 16 * NT + 8;
   float* sKt = a16_smem;
   float* sVt = sKt + 64 * TP;
@@ -223,7 +221,6 @@ __global__ __launch_bounds__(64 * NT) void attention16_bwd_q_kernel(const float*
   const int na = causal ? qt + 1 : NT;
   auto head = [&](int item) { return qkv + (size_t)(item / H) * L * ld + (size_t)(item % H) * A16_HD; };
   f32x4 kst[4], vst[4];
-  const int item = blockIdx.x;  // = b * H + h
   a16_fetch<NT>(head(item) + d, ld, L, kst);
   a16_fetch<NT>(head(item) + 2 * d, ld, L, vst);
   const int b = item / H, h = item % H;
@@ -244,7 +241,6 @@ __global__ __launch_bounds__(64 * NT) void attention16_bwd_q_kernel(const float*
   a16_put<NT>(sKt, kst, L);
   a16_put<NT>(sVt, vst, L);
   Di = a16_allreduce_sum(Di);
-  if (q_tok < L && g == 0) Dbuf[((size_t)b * H + h) * L + q_tok] = Di;
   __syncthreads();
   f32x4 s[A16_MAX_TILES], dp[A16_MAX_TILES];
   A16_SWITCH_SCORES(na, sKt, qf, s)
@@ -268,19 +264,19 @@ __global__ __launch_bounds__(64 * NT) void attention16_bwd_q_kernel(const float*
 }
 
 // dK/dV pass (own = 16 keys).  S = Q K^T ; P = exp2(S c - lse) ; dP = dO V^T ; dS = P (dP - D) / 8 ;
-// dV^T = dO^T P ; dK^T = Q^T dS.  lse and D vary with the register index (rows = queries): 4-float groups from LDS.
+// dV^T = dO^T P ; dK^T = Q^T dS.  lse and D vary with the register index (rows = queries): 4-float groups from LDS;
+// D is recomputed here from the staged dO rows and the matching O rows.
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void attention16_bwd_kv_kernel(const float* __restrict__ qkv,
-                                                                     const float* __restrict__ dout,
-                                                                     const float* __restrict__ lse,
-                                                                     const float* __restrict__ Dbuf,
-                                                                     float* __restrict__ dqkv, int L, int H, int causal) {
-  extern __shared__ __attribute__((aligned(16))) float a16_smem[];
+__device__ __forceinline__ void attention16_bwd_kv_body(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                        const float* __restrict__ out, const float* __restrict__ lse,
+                                                        float* __restrict__ dqkv, int L, int H, int causal, int item,
+                                                        float* a16_smem) {
   constexpr int Lp = 16 * NT, TP = Lp + 8;
   float* sQt = a16_smem;
   float* sGt = sQt + 64 * TP;
   float* sLse = sGt + 64 * TP;  // [Lp], log2 units
   float* sD = sLse + Lp;
+  float* sPart = sD + Lp;       // [16 feature chunks][Lp]: partial dO . O sums of the staging threads
   const int lane = threadIdx.x & 63;
   const int kt = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int d = H * A16_HD;
@@ -296,19 +292,31 @@ __global__ __launch_bounds__(64 * NT) void attention16_bwd_kv_kernel(const float
   auto qhead = [&](int item) { return qkv + (size_t)(item / H) * L * ld + (size_t)(item % H) * A16_HD; };
   auto ghead = [&](int item) { return dout + (size_t)(item / H) * L * d + (size_t)(item % H) * A16_HD; };
   const int vtok = min((int)threadIdx.x, L - 1);  // thread i < 16 NT carries element i of the head's lse / D vectors
-  f32x4 qst[4], gst[4];
-  const int item = blockIdx.x;  // = b * H + h
+  f32x4 qst[4], gst[4], ost[4];
   a16_fetch<NT>(qhead(item), ld, L, qst);
   a16_fetch<NT>(ghead(item), (size_t)d, L, gst);
+  a16_fetch<NT>(out + (size_t)(item / H) * L * d + (size_t)(item % H) * A16_HD, (size_t)d, L, ost);
   const int b = item / H, h = item % H;
   float kf[16], vf[16];
   a16_load_own(qhead(item) + d, ld, k_cl, lane, kf);
   a16_load_own(qhead(item) + 2 * d, ld, k_cl, lane, vf);
   const float lse_i = lse[(size_t)item * L + vtok];  // item = b * H + h
-  const float d_i = Dbuf[(size_t)item * L + vtok];
   a16_put<NT>(sQt, qst, L);
   a16_put<NT>(sGt, gst, L);
+  // D_i = dO_i . O_i from the rows this pass stages anyway (the dQ pass computes its own copy in registers, so the two
+  // passes do not depend on each other and run as ONE launch): each staging thread holds 4 features of 4 (chunk, token)
+  // pairs; the 16 chunk sums of a token are added in chunk order by the thread that owns the token => reproducible
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int idx = (int)threadIdx.x + k * 64 * NT;
+    const int c = idx / Lp, tok = idx - c * Lp;
+    sPart[c * Lp + tok] = fmaf(gst[k][3], ost[k][3], fmaf(gst[k][2], ost[k][2], fmaf(gst[k][1], ost[k][1], gst[k][0] * ost[k][0])));
+  }
+  __syncthreads();
   if ((int)threadIdx.x < Lp) {
+    float d_i = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d_i += sPart[c * Lp + threadIdx.x];
     sLse[threadIdx.x] = (int)threadIdx.x < L ? lse_i * A16_LOG2E : 0.f;
     sD[threadIdx.x] = (int)threadIdx.x < L ? d_i : 0.f;
   }
@@ -345,6 +353,22 @@ __global__ __launch_bounds__(64 * NT) void attention16_bwd_kv_kernel(const float
   }
 }
 
+// The backward as ONE launch: workgroup 2 i takes the dQ pass of head i, workgroup 2 i + 1 its dK/dV pass (neighbours in
+// dispatch order, so the head's q, k, v, dO rows are fetched from HBM once and found in L2 by the other).  Round 2 ran
+// them as two launches with D handed through memory; at the per-rank sizes of the 8-GPU step each was ~15 us of work
+// behind its own launch.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attention16_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                  const float* __restrict__ out, const float* __restrict__ lse,
+                                                                  float* __restrict__ dqkv, int L, int H, int causal) {
+  extern __shared__ __attribute__((aligned(16))) float a16_smem[];
+  const int item = blockIdx.x >> 1;  // = b * H + h
+  if (blockIdx.x & 1)
+    attention16_bwd_kv_body<NT>(qkv, dout, out, lse, dqkv, L, H, causal, item, a16_smem);
+  else
+    attention16_bwd_q_body<NT>(qkv, dout, out, lse, dqkv, L, H, causal, item, a16_smem);
+}
+
 // ---- host side (called from attention_mfma.hip) -------------------------------------------------------------
 
 bool attention16_enabled(int seq) {
@@ -352,8 +376,8 @@ bool attention16_enabled(int seq) {
   return cfg != 0 && seq <= 16 * A16_MAX_TILES;
 }
 
-static size_t a16_lds(int nt, bool vectors) {
-  return ((size_t)2 * 64 * (16 * nt + 8) + (vectors ? 2 * (size_t)16 * nt : 0)) * sizeof(float);
+static size_t a16_lds(int nt, bool vectors) {  // vectors: lse, D and the 16 partial-D rows of the dK/dV pass
+  return ((size_t)2 * 64 * (16 * nt + 8) + (vectors ? 18 * (size_t)16 * nt : 0)) * sizeof(float);
 }
 
 template <int NT>
@@ -372,19 +396,15 @@ static int a16_fwd(const float* qkv, float* out, float* lse, int batch, int seq,
 template <int NT>
 static int a16_bwd(const float* qkv, const float* dout, const float* out, const float* lse, float* dqkv, float* work,
                    int batch, int seq, int heads, int causal, hipStream_t st) {
+  (void)work;  // D_i no longer travels through memory
   static bool attr = false;
   if (!attr && a16_lds(NT, true) > 48 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention16_bwd_q_kernel<NT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)a16_lds(NT, true));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention16_bwd_kv_kernel<NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention16_bwd_kernel<NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)a16_lds(NT, true));
     attr = true;
   }
-  hipLaunchKernelGGL(attention16_bwd_q_kernel<NT>, dim3(batch * heads), dim3(64 * NT), a16_lds(NT, false), st, qkv, dout, out,
-                     lse, dqkv, work, seq, heads, causal);
-  CLIPFS_CHECK(launch_status());
-  hipLaunchKernelGGL(attention16_bwd_kv_kernel<NT>, dim3(batch * heads), dim3(64 * NT), a16_lds(NT, true), st, qkv, dout, lse,
-                     work, dqkv, seq, heads, causal);
+  hipLaunchKernelGGL(attention16_bwd_kernel<NT>, dim3(2 * batch * heads), dim3(64 * NT), a16_lds(NT, true), st, qkv, dout, out,
+                     lse, dqkv, seq, heads, causal);
   return launch_status();
 }
 
