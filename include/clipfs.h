@@ -162,12 +162,12 @@ int clipfs_layernorm_bwd_f16(const float* dy, const float* x, int ldx, const flo
  * clipfs_lora_down on y (same Philox counters, so clipfs_lora_bwd regenerates the same masks; t agrees to fp32 summation
  * order).  Replaces ln_1 + lora_A(dropout(x)) of the adapted q/k/v projections, jclip/model.py:115 with
  * lora_train_vlp.py:296-306.  Covered: nseg == 3, r in {1, 2, 4} (clipfs_layernorm_fwd_lora_ok); other shapes take the
- * two separate calls. */
+ * two separate calls.  keep_bits (may be NULL): as for clipfs_lora_down. */
 int clipfs_layernorm_fwd_lora_ok(int width, int r, int nseg);
 int clipfs_layernorm_fwd_lora(const float* x, int ldx, const float* gamma, const float* beta, float* y, void* y16,
                               float* mean, float* rstd, int rows, int width, float eps, const float* A, float* t, int r,
                               int nseg, unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
-                              void* stream);
+                              void* keep_bits, void* stream);
 
 /* ------------------------------------------------------------- attention --
  * qkv [B*L, 3*d] (q | k | v, head h at columns h*64..), out [B*L, d] heads merged.
@@ -210,7 +210,12 @@ int clipfs_attention_f16_bwd(const void* qkv, int qkv_f16, const void* dout, int
  * one-process run); p = 0 or seed == 0 disables dropout.  seg_mask bit s = 0 leaves t[:, s*r..] = 0. */
 int clipfs_lora_down(const float* x, const float* A, float* t, int rows, int width, int r, int nseg,
                      unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
-                     void* stream);
+                     void* keep_bits, void* stream);
+/* keep_bits (may be NULL): uint16 [rows, width/4]; with dropout active the forward records its masks there -- bit
+ * 4*s + e of entry (m, c) set <=> element (m, 4*c + e) was kept for segment s -- and clipfs_lora_bwd / _f16dy given the
+ * same buffer read them instead of evaluating Philox again (identical masks by construction; the adapter's dA / dx
+ * products were VALU-bound on the generator).  Matrix-core kernels only: clipfs_lora_keep_bits_ok(...) != 0. */
+int clipfs_lora_keep_bits_ok(int width, int segw, int r, int nseg);
 /* Backward of the adapter pair for one linear with nseg stacked segments:
  *   dt[m, s*r+j]  = scale * sum_n dy[m, s*segw + n] * B[s*segw + n, j]
  *   dB[s*segw+n,j] += scale * sum_m dy[m, s*segw+n] * t[m, s*r+j]
@@ -221,7 +226,7 @@ size_t clipfs_lora_bwd_work_floats(int rows, int width, int r, int nseg);
 int clipfs_lora_bwd(const float* dy, const float* x, const float* t, const float* A, const float* B,
                     float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
                     int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
-                    uint32_t drow0, float* work, void* stream);
+                    uint32_t drow0, const void* keep_bits, float* work, void* stream);
 /* The same with dy given as its f16 image [rows, nseg*segw] (fp16 storage mode: the tensor the dgrad GEMM consumes), so
  * that the two passes over dy move half the bytes and the fp32 dy need not exist.  Matrix-core kernels only:
  * clipfs_lora_bwd_f16dy_ok(width, segw, r, nseg) != 0 says a shape is covered (r <= 16, width % 128 == 0, ...). */
@@ -229,7 +234,7 @@ int clipfs_lora_bwd_f16dy_ok(int width, int segw, int r, int nseg);
 int clipfs_lora_bwd_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B,
                           float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
                           int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
-                          uint32_t drow0, float* work, void* stream);
+                          uint32_t drow0, const void* keep_bits, float* work, void* stream);
 
 /* --------------------------------------------------------- token assembly --
  * vit: x[b,0,:] = class_embedding + pos[0]; x[b, 1+P+i, :] = vpt[i]  (jclip/model.py:109-114,

@@ -90,18 +90,19 @@ SIGNATURES = {
     "clipfs_layernorm_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_layernorm_fwd_f16": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "clipfs_layernorm_fwd_lora_ok": (_i, [_i, _i, _i]),
-    "clipfs_layernorm_fwd_lora": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _i, _i, _u, _f, _u64, _u32, _u32, _p]),
+    "clipfs_layernorm_fwd_lora": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _i, _i, _u, _f, _u64, _u32, _u32, _p, _p]),
     "clipfs_layernorm_bwd_f16": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "clipfs_attention_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_attention_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_attention_lse_floats": (_sz, [_i, _i, _i]),
     "clipfs_attention_f16_fwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "clipfs_attention_f16_bwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "clipfs_lora_down": (_i, [_p, _p, _p, _i, _i, _i, _i, _u, _f, _u64, _u32, _u32, _p]),
+    "clipfs_lora_keep_bits_ok": (_i, [_i, _i, _i, _i]),
+    "clipfs_lora_down": (_i, [_p, _p, _p, _i, _i, _i, _i, _u, _f, _u64, _u32, _u32, _p, _p]),
     "clipfs_lora_bwd_work_floats": (_sz, [_i, _i, _i, _i]),
-    "clipfs_lora_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _u32, _p, _p]),
+    "clipfs_lora_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _u32, _p, _p, _p]),
     "clipfs_lora_bwd_f16dy_ok": (_i, [_i, _i, _i, _i]),
-    "clipfs_lora_bwd_f16dy": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _u32, _p, _p]),
+    "clipfs_lora_bwd_f16dy": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _u, _f, _f, _u64, _u32, _u32, _p, _p, _p]),
     "clipfs_vit_fill_special": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "clipfs_text_embed": (_i, [_p, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
     "clipfs_token_rows_grad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

@@ -149,7 +149,8 @@ def layernorm_fwd(x, gamma, beta, *, ldx=None, rows=None, save_stats=False, eps=
     return (y, mean, rstd) if save_stats else y
 
 
-def layernorm_fwd_lora(x, gamma, beta, A, r, nseg=3, *, seg_mask=None, p=0.0, seed=0, stream_base=0, row0=0, eps=1e-5):
+def layernorm_fwd_lora(x, gamma, beta, A, r, nseg=3, *, seg_mask=None, p=0.0, seed=0, stream_base=0, row0=0, eps=1e-5,
+                       keep_bits=None):
     """LayerNorm + adapter down-projection in one pass: returns (y, t, mean, rstd)."""
     width = gamma.numel()
     rows = x.numel() // width
@@ -163,7 +164,8 @@ def layernorm_fwd_lora(x, gamma, beta, A, r, nseg=3, *, seg_mask=None, p=0.0, se
     if seg_mask is None:
         seg_mask = (1 << nseg) - 1
     check(lib.clipfs_layernorm_fwd_lora(_p(_f32(x)), width, _p(gamma), _p(beta), _p(y), None, _p(mean), _p(rstd), rows, width,
-                                        eps, _p(_f32(A)), _p(t), r, nseg, seg_mask, p, seed, stream_base, row0, _stream()),
+                                        eps, _p(_f32(A)), _p(t), r, nseg, seg_mask, p, seed, stream_base, row0, _p(keep_bits),
+                                        _stream()),
           "layernorm_fwd_lora")
     return y, t, mean, rstd
 
@@ -220,17 +222,22 @@ def attention_bwd(qkv, dout, batch, seq, heads, causal, out=None, lse=None):
     return dqkv
 
 
-def lora_down(x, A, r, nseg, seg_mask=None, p=0.0, seed=0, stream_base=0, row0=0):
+def lora_keep_bits(rows, width, device):
+    """Buffer for the dropout masks an adapted projection records in its forward (uint16 per float4 of the input)."""
+    return torch.zeros(rows, width // 4, device=device, dtype=torch.int16)
+
+
+def lora_down(x, A, r, nseg, seg_mask=None, p=0.0, seed=0, stream_base=0, row0=0, keep_bits=None):
     rows, width = x.shape
     t = torch.empty(rows, nseg * r, device=x.device, dtype=torch.float32)
     if seg_mask is None:
         seg_mask = (1 << nseg) - 1
     check(_lib.load().clipfs_lora_down(_p(_f32(x)), _p(_f32(A)), _p(t), rows, width, r, nseg, seg_mask, p, seed,
-                                       stream_base, row0, _stream()), "lora_down")
+                                       stream_base, row0, _p(keep_bits), _stream()), "lora_down")
     return t
 
 
-def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_base=0, seg_mask=None, row0=0):
+def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_base=0, seg_mask=None, row0=0, keep_bits=None):
     rows, width = x.shape
     nseg = dy.shape[1] // width
     r = B.shape[1]
@@ -244,11 +251,11 @@ def lora_bwd(dy, x, t, A, B, dA, dB, *, dx=None, scale, p=0.0, seed=0, stream_ba
         assert dy.is_contiguous()
         check(lib.clipfs_lora_bwd_f16dy(_p(dy), _p(_f32(x)), _p(_f32(t)), _p(_f32(A)), _p(_f32(B)), _p(dt), _p(dA),
                                         _p(dB), _p(dx), rows, width, width, r, nseg, seg_mask, scale, p, seed, stream_base,
-                                        row0, _p(work), _stream()), "lora_bwd_f16dy")
+                                        row0, _p(keep_bits), _p(work), _stream()), "lora_bwd_f16dy")
         return dt
     check(lib.clipfs_lora_bwd(_p(_f32(dy)), _p(_f32(x)), _p(_f32(t)), _p(_f32(A)), _p(_f32(B)), _p(dt), _p(dA),
                               _p(dB), _p(dx), rows, width, width, r, nseg, seg_mask, scale, p, seed, stream_base,
-                              row0, _p(work), _stream()), "lora_bwd")
+                              row0, _p(keep_bits), _p(work), _stream()), "lora_bwd")
     return dt
 
 

@@ -99,6 +99,17 @@ __device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint32_t stream,
                      r.w >= thr ? inv_keep : 0.f);
 }
 
+// The same multipliers from / to 4 stored keep bits (bit e = column 4*col4 + e kept): the forward pass of an adapted
+// projection records its masks as 4 bits per segment and float4 so that the backward reads 2 bytes per float4 instead of
+// evaluating Philox again (three 10-round evaluations per float4 made the adapter's dA / dx kernels VALU-bound).
+__device__ __forceinline__ float4 keep_scale4(uint32_t bits, float inv_keep) {
+  return make_float4((bits & 1u) ? inv_keep : 0.f, (bits & 2u) ? inv_keep : 0.f, (bits & 4u) ? inv_keep : 0.f,
+                     (bits & 8u) ? inv_keep : 0.f);
+}
+__device__ __forceinline__ uint32_t keep_bits4(const float4& mk) {
+  return (mk.x != 0.f ? 1u : 0u) | (mk.y != 0.f ? 2u : 0u) | (mk.z != 0.f ? 4u : 0u) | (mk.w != 0.f ? 8u : 0u);
+}
+
 __device__ __forceinline__ float quick_gelu(float u) { return u / (1.f + __expf(-1.702f * u)); }
 __device__ __forceinline__ float quick_gelu_grad(float u) {
   const float s = 1.f / (1.f + __expf(-1.702f * u));

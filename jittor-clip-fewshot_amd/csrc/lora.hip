@@ -274,16 +274,16 @@ static inline int lora_slice_rows(int rows) {
 // lora_mfma.hip
 bool lora_mfma_ok(int width, int segw, int r, int nseg);
 int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
-                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, hipStream_t st);
+                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, uint16_t* keep_bits, hipStream_t st);
 typedef void (*lora_reduce2_fn)(const float*, float*, size_t, int, float, const float*, float*, size_t, int, float, hipStream_t);
 int lora_bwd_mfma_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                         float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
-                        float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                        lora_reduce2_fn reduce);
+                        float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, const uint16_t* keep_bits,
+                        float* work, hipStream_t st, lora_reduce2_fn reduce);
 int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                   float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
-                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                  lora_reduce2_fn reduce);
+                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, const uint16_t* keep_bits, float* work,
+                  hipStream_t st, lora_reduce2_fn reduce);
 
 // the dB and dA slice sums of one adapter backward in one launch (blocks [0, nblk0) take the first)
 static void launch_reduce_slices2(const float* part0, float* out0, size_t n0, int slices0, float scale0, const float* part1,
@@ -302,15 +302,25 @@ static bool use_lora_mfma() {
 
 using namespace clipfs;
 
+// whether the forward can record its dropout masks as keep bits for the backward (matrix-core kernels, <= 4 segments)
+extern "C" int clipfs_lora_keep_bits_ok(int width, int segw, int r, int nseg) {
+  static const int cfg = getenv("CLIPFS_LORA_KEEP_BITS") ? atoi(getenv("CLIPFS_LORA_KEEP_BITS")) : 1;  // 0: Philox again in the backward (A/B aid)
+  return (cfg != 0 && use_lora_mfma() && lora_mfma_ok(width, segw, r, nseg) && segw == width && nseg <= 4) ? 1 : 0;
+}
+
 extern "C" int clipfs_lora_down(const float* x, const float* A, float* t, int rows, int width, int r, int nseg,
-                                unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, void* stream) {
+                                unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, void* keep_bits,
+                                void* stream) {
   CLIPFS_REQUIRE(x && A && t, "lora_down: null pointer");
+  CLIPFS_REQUIRE(!keep_bits || clipfs_lora_keep_bits_ok(width, width, r, nseg),
+                 "lora_down: keep bits are recorded by the matrix-core kernels only (width %d r %d nseg %d)", width, r, nseg);
   CLIPFS_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0 && width <= 256 * LORA_MAX_CHUNKS, "lora_down: width %d unsupported", width);
   CLIPFS_REQUIRE(r > 0 && r <= 64 && nseg > 0 && nseg <= 4 && nseg * r <= LORA_MAX_OUT, "lora_down: r %d nseg %d unsupported", r, nseg);
   CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_down: dropout p %f out of range", (double)p);
   CLIPFS_REQUIRE(aligned16(x) && aligned16(A), "lora_down: misaligned pointer");
   if (use_lora_mfma() && lora_mfma_ok(width, width, r, nseg))
-    return lora_down_mfma(x, A, t, rows, width, r, nseg, seg_mask, p, seed, stream_base, drow0, (hipStream_t)stream);
+    return lora_down_mfma(x, A, t, rows, width, r, nseg, seg_mask, p, seed, stream_base, drow0,
+                          reinterpret_cast<uint16_t*>(keep_bits), (hipStream_t)stream);
   hipLaunchKernelGGL(lora_down_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, A, t, rows, width, r,
                      nseg, seg_mask, p, seed, stream_base, drow0);
   return launch_status();
@@ -375,15 +385,17 @@ static int lora_bwd_r(const float* dy, const float* x, const float* t, const flo
 extern "C" int clipfs_lora_bwd(const float* dy, const float* x, const float* t, const float* A, const float* B,
                                float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
                                int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
-                               float* work, void* stream) {
+                               const void* keep_bits, float* work, void* stream) {
   CLIPFS_REQUIRE(dy && x && t && A && B && dt && dA && dB && work, "lora_bwd: null pointer");
+  CLIPFS_REQUIRE(!keep_bits || (clipfs_lora_keep_bits_ok(width, segw, r, nseg) && aligned16(dy) && aligned16(dx ? dx : x)),
+                 "lora_bwd: keep bits are read by the matrix-core kernels only (width %d r %d nseg %d)", width, r, nseg);
   CLIPFS_REQUIRE(rows > 0 && width > 0 && (width & 3) == 0 && segw == width, "lora_bwd: width %d segw %d unsupported (segw must equal width)", width, segw);
   CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_bwd: dropout p out of range");
   CLIPFS_REQUIRE(aligned16(x) && aligned16(A) && aligned16(work) && (!dx || aligned16(dx)), "lora_bwd: misaligned pointer");
   hipStream_t st = (hipStream_t)stream;
   if (use_lora_mfma() && lora_mfma_ok(width, segw, r, nseg) && aligned16(dy) && aligned16(dx ? dx : x))
     return lora_bwd_mfma(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base, drow0,
-                         work, st, launch_reduce_slices2);
+                         reinterpret_cast<const uint16_t*>(keep_bits), work, st, launch_reduce_slices2);
 #define CLIPFS_LORA_CASE(RR)                                                                                       \
   case RR:                                                                                                         \
     return lora_bwd_r<RR>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, nseg, seg_mask, scale, p, seed,       \
@@ -411,13 +423,14 @@ extern "C" int clipfs_lora_bwd_f16dy_ok(int width, int segw, int r, int nseg) {
 extern "C" int clipfs_lora_bwd_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B,
                                      float* dt, float* dA, float* dB, float* dx, int rows, int width, int segw, int r,
                                      int nseg, unsigned seg_mask, float scale, float p, uint64_t seed, uint32_t stream_base,
-                                     uint32_t drow0, float* work, void* stream) {
+                                     uint32_t drow0, const void* keep_bits, float* work, void* stream) {
   CLIPFS_REQUIRE(dy16 && x && t && A && B && dt && dA && dB && work, "lora_bwd_f16dy: null pointer");
   CLIPFS_REQUIRE(rows > 0 && clipfs_lora_bwd_f16dy_ok(width, segw, r, nseg),
                  "lora_bwd_f16dy: width %d segw %d r %d nseg %d is outside the matrix-core kernels", width, segw, r, nseg);
   CLIPFS_REQUIRE(p >= 0.f && p < 1.f, "lora_bwd_f16dy: dropout p out of range");
   CLIPFS_REQUIRE(aligned16(dy16) && aligned16(x) && aligned16(A) && aligned16(work) && (!dx || aligned16(dx)),
                  "lora_bwd_f16dy: misaligned pointer");
+  CLIPFS_REQUIRE(!keep_bits || clipfs_lora_keep_bits_ok(width, segw, r, nseg), "lora_bwd_f16dy: keep bits not covered");
   return lora_bwd_mfma_f16dy(dy16, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, nseg, seg_mask, scale, p, seed, stream_base,
-                             drow0, work, (hipStream_t)stream, launch_reduce_slices2);
+                             drow0, reinterpret_cast<const uint16_t*>(keep_bits), work, (hipStream_t)stream, launch_reduce_slices2);
 }

@@ -64,7 +64,8 @@ template <int NSEG>
 __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __restrict__ x, const float* __restrict__ A,
                                                              float* __restrict__ t, int rows, int width, int r,
                                                              unsigned seg_mask, float p, uint64_t seed,
-                                                             uint32_t stream_base, uint32_t drow0) {
+                                                             uint32_t stream_base, uint32_t drow0,
+                                                             uint16_t* __restrict__ keep_bits) {
   __shared__ f32x4 red[3 * NSEG * 64];
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = threadIdx.x >> 6;
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __rest
       xv[u] = ld4(xr + min(cu, cend - 16));
       if (cu >= cend) xv[u] = zero4();
     }
+    uint32_t kb[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int s = 0; s < NSEG; ++s) {
       if (!((seg_mask >> s) & 1u)) continue;
@@ -103,10 +105,16 @@ __global__ __launch_bounds__(256) void lora_down_mfma_kernel(const float* __rest
           xs[1] *= mk.y;
           xs[2] *= mk.z;
           xs[3] *= mk.w;
+          kb[u] |= keep_bits4(mk) << (4 * s);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[s] = mfma16(xs[e], wv[u][e], acc[s]);
       }
+    }
+    if (keep_bits && drop && row0 + li < rows) {  // the masks of this pass, for the backward (4 bits per segment and float4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c0 + 16 * u < cend) keep_bits[(size_t)m * (width >> 2) + ((c0 + 16 * u) >> 2) + kg] = (uint16_t)kb[u];
     }
   }
   block_sum4<NSEG>(acc, red, wave, lane);
@@ -226,7 +234,8 @@ template <int NSEG>
 __device__ __forceinline__ void lora_da_mfma_body(const float* __restrict__ x, const float* __restrict__ dt,
                                                   float* __restrict__ part, int rows, int width, int r, unsigned seg_mask,
                                                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0,
-                                                  int rows_per_slice, int bx, int by) {
+                                                  int rows_per_slice, int bx, int by,
+                                                  const uint16_t* __restrict__ keep_bits) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int k0 = (bx * 4 + (threadIdx.x >> 6)) * 64;
   if (k0 >= width) return;
@@ -248,12 +257,14 @@ __device__ __forceinline__ void lora_da_mfma_body(const float* __restrict__ x, c
     f32x4 xv[2];
     float g[2][NSEG];
     int mcs[2];
+    uint32_t kbu[2] = {0u, 0u};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int m = mb + 4 * u + kg;
       const bool ok = m < m1;
       mcs[u] = ok ? m : m1 - 1;
       xv[u] = ld4(xp + (size_t)mcs[u] * width);
+      if (keep_bits) kbu[u] = keep_bits[(size_t)mcs[u] * (width >> 2) + c4];
       if (!ok) xv[u] = zero4();
 #pragma unroll
       for (int s = 0; s < NSEG; ++s) g[u][s] = dp[(size_t)mcs[u] * tw + s * r];
@@ -265,7 +276,8 @@ __device__ __forceinline__ void lora_da_mfma_body(const float* __restrict__ x, c
         if (!((seg_mask >> s) & 1u)) continue;
         f32x4 xs = xv[u];
         if (drop) {
-          const float4 mk = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)mcs[u], c4, thr, inv_keep);
+          const float4 mk = keep_bits ? keep_scale4(kbu[u] >> (4 * s), inv_keep)
+                                      : dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)mcs[u], c4, thr, inv_keep);
           xs[0] *= mk.x;
           xs[1] *= mk.y;
           xs[2] *= mk.z;
@@ -296,7 +308,8 @@ __device__ __forceinline__ void lora_da_mfma_body(const float* __restrict__ x, c
 template <int NSEG, int RQ>  // RQ = ceil(r / 4) MFMA K-steps
 __device__ __forceinline__ void lora_dx_mfma_body(const float* __restrict__ dt, const float* __restrict__ A,
                                                   float* __restrict__ dx, int rows, int width, int r, unsigned seg_mask,
-                                                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, int bx) {
+                                                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, int bx,
+                                                  const uint16_t* __restrict__ keep_bits) {
   const int lane = threadIdx.x & 63, li = lane & 15, kg = lane >> 4;
   const int wave = threadIdx.x >> 6;
   const int row0 = bx * 16;
@@ -323,9 +336,11 @@ __device__ __forceinline__ void lora_dx_mfma_body(const float* __restrict__ dt, 
   for (int k0 = wave * cw; k0 < (wave + 1) * cw; k0 += 32) {  // two 16-column tiles, loads first (cw % 32 == 0)
     f32x4 tot[2];
     float av[2][NSEG][RQ];
+    uint32_t kbu[2] = {0u, 0u};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       tot[u] = ld4(xr + k0 + 16 * u);
+      if (keep_bits) kbu[u] = keep_bits[(size_t)mc * (width >> 2) + ((k0 + 16 * u) >> 2) + kg];
 #pragma unroll
       for (int s = 0; s < NSEG; ++s)
 #pragma unroll
@@ -340,7 +355,8 @@ __device__ __forceinline__ void lora_dx_mfma_body(const float* __restrict__ dt, 
 #pragma unroll
         for (int q = 0; q < RQ; ++q) acc = mfma16(av[u][s][q], dtv[s][q], acc);
         if (drop) {
-          const float4 mk = dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)mc, (uint32_t)(((k0 + 16 * u) >> 2) + kg), thr, inv_keep);
+          const float4 mk = keep_bits ? keep_scale4(kbu[u] >> (4 * s), inv_keep)
+                                      : dropout_scale4(seed, stream_base + s, drow0 + (uint32_t)mc, (uint32_t)(((k0 + 16 * u) >> 2) + kg), thr, inv_keep);
           acc[0] *= mk.x;
           acc[1] *= mk.y;
           acc[2] *= mk.z;
@@ -378,13 +394,13 @@ __global__ __launch_bounds__(256) void lora_da_dx_mfma_kernel(const float* __res
                                                               float* __restrict__ dx, int rows, int width, int r,
                                                               unsigned seg_mask, float p, uint64_t seed,
                                                               uint32_t stream_base, uint32_t drow0, int rows_per_slice,
-                                                              int gx_a, int n_da) {
+                                                              int gx_a, int n_da, const uint16_t* __restrict__ keep_bits) {
   const int b = blockIdx.x;
   if (b < n_da)
     lora_da_mfma_body<NSEG>(x, dt, part_a, rows, width, r, seg_mask, p, seed, stream_base, drow0, rows_per_slice, b % gx_a,
-                            b / gx_a);
+                            b / gx_a, keep_bits);
   else
-    lora_dx_mfma_body<NSEG, RQ>(dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, b - n_da);
+    lora_dx_mfma_body<NSEG, RQ>(dt, A, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, b - n_da, keep_bits);
 }
 
 // ---- host side (called from lora.hip) ---------------------------------------------------------------------
@@ -402,23 +418,23 @@ static int lora_mfma_slice_rows(int rows, int col_groups) {
 }
 
 int lora_down_mfma(const float* x, const float* A, float* t, int rows, int width, int r, int nseg, unsigned seg_mask,
-                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, hipStream_t st) {
+                   float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, uint16_t* keep_bits, hipStream_t st) {
   const dim3 grid((rows + 15) / 16);
   if (nseg == 1)
-    hipLaunchKernelGGL((lora_down_mfma_kernel<1>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base, drow0);
+    hipLaunchKernelGGL((lora_down_mfma_kernel<1>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base, drow0, keep_bits);
   else
-    hipLaunchKernelGGL((lora_down_mfma_kernel<3>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base, drow0);
+    hipLaunchKernelGGL((lora_down_mfma_kernel<3>), grid, dim3(256), 0, st, x, A, t, rows, width, r, seg_mask, p, seed, stream_base, drow0, keep_bits);
   return launch_status();
 }
 
 template <int NSEG, int RQ>
 static void launch_da_dx(const float* x, const float* dt, const float* A, float* part_a, float* dx, int rows, int width, int r,
                          unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, int sr_a, int slices_a,
-                         hipStream_t st) {
+                         const uint16_t* keep_bits, hipStream_t st) {
   const int gx_a = (width + 255) / 256, n_da = gx_a * slices_a;
   const int n_dx = dx ? (rows + 15) / 16 : 0;
   hipLaunchKernelGGL((lora_da_dx_mfma_kernel<NSEG, RQ>), dim3(n_da + n_dx), dim3(256), 0, st, x, dt, A, part_a, dx, rows, width,
-                     r, seg_mask, p, seed, stream_base, drow0, sr_a, gx_a, n_da);
+                     r, seg_mask, p, seed, stream_base, drow0, sr_a, gx_a, n_da, keep_bits);
 }
 
 // reduce2(part_b, dB, nb, slices_b, scale_b, part_a, dA, na, slices_a, scale_a): both slice sums in one launch
@@ -427,8 +443,8 @@ typedef void (*lora_reduce2_fn)(const float*, float*, size_t, int, float, const 
 template <int NSEG, typename TY>
 static int lora_bwd_mfma_n(const TY* dy, const float* x, const float* t, const float* A, const float* B, float* dt,
                            float* dA, float* dB, float* dx, int rows, int width, int segw, int r, unsigned seg_mask,
-                           float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                           lora_reduce2_fn reduce2) {
+                           float scale, float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, const uint16_t* keep_bits,
+                           float* work, hipStream_t st, lora_reduce2_fn reduce2) {
   const int cols = NSEG * segw;
   const int sr_b = lora_mfma_slice_rows(rows, cols / 64), slices_b = (rows + sr_b - 1) / sr_b;
   const int sr_a = lora_mfma_slice_rows(rows, width / 64), slices_a = (rows + sr_a - 1) / sr_a;
@@ -444,16 +460,16 @@ static int lora_bwd_mfma_n(const TY* dy, const float* x, const float* t, const f
   // 2: dA partials || dx
   switch ((r + 3) / 4) {
     case 1:
-      launch_da_dx<NSEG, 1>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      launch_da_dx<NSEG, 1>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, keep_bits, st);
       break;
     case 2:
-      launch_da_dx<NSEG, 2>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      launch_da_dx<NSEG, 2>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, keep_bits, st);
       break;
     case 3:
-      launch_da_dx<NSEG, 3>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      launch_da_dx<NSEG, 3>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, keep_bits, st);
       break;
     default:
-      launch_da_dx<NSEG, 4>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, st);
+      launch_da_dx<NSEG, 4>(x, dt, A, part_a, dx, rows, width, r, seg_mask, p, seed, stream_base, drow0, sr_a, slices_a, keep_bits, st);
       break;
   }
   CLIPFS_CHECK(launch_status());
@@ -464,26 +480,26 @@ static int lora_bwd_mfma_n(const TY* dy, const float* x, const float* t, const f
 
 int lora_bwd_mfma(const float* dy, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                   float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
-                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                  lora_reduce2_fn reduce) {
+                  float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, const uint16_t* keep_bits, float* work,
+                  hipStream_t st, lora_reduce2_fn reduce) {
   if (nseg == 1)
     return lora_bwd_mfma_n<1, float>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
-                                     work, st, reduce);
+                                     keep_bits, work, st, reduce);
   return lora_bwd_mfma_n<3, float>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base, drow0,
-                                   work, st, reduce);
+                                   keep_bits, work, st, reduce);
 }
 
 // the same with dy given as its f16 image [rows, nseg * segw] (fp16 storage mode)
 int lora_bwd_mfma_f16dy(const void* dy16, const float* x, const float* t, const float* A, const float* B, float* dt, float* dA,
                         float* dB, float* dx, int rows, int width, int segw, int r, int nseg, unsigned seg_mask, float scale,
-                        float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, float* work, hipStream_t st,
-                        lora_reduce2_fn reduce) {
+                        float p, uint64_t seed, uint32_t stream_base, uint32_t drow0, const uint16_t* keep_bits,
+                        float* work, hipStream_t st, lora_reduce2_fn reduce) {
   const _Float16* dy = reinterpret_cast<const _Float16*>(dy16);
   if (nseg == 1)
     return lora_bwd_mfma_n<1, _Float16>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
-                                        drow0, work, st, reduce);
+                                        drow0, keep_bits, work, st, reduce);
   return lora_bwd_mfma_n<3, _Float16>(dy, x, t, A, B, dt, dA, dB, dx, rows, width, segw, r, seg_mask, scale, p, seed, stream_base,
-                                      drow0, work, st, reduce);
+                                      drow0, keep_bits, work, st, reduce);
 }
 
 }  // namespace clipfs

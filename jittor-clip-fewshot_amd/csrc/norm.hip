@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lora_kernel(const float* x,
                                                                  int rows, int width, float eps, _Float16* __restrict__ y16,
                                                                  const float* __restrict__ A, float* __restrict__ t,
                                                                  unsigned seg_mask, float p, uint64_t seed,
-                                                                 uint32_t stream_base, uint32_t drow0) {
+                                                                 uint32_t stream_base, uint32_t drow0,
+                                                                 uint16_t* __restrict__ keep_bits) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lora_kernel(const float* x,
       o.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (yr) yr[c] = o;
       if (yh) yh[c] = f16x4{(_Float16)o.x, (_Float16)o.y, (_Float16)o.z, (_Float16)o.w};
+      uint32_t kb = 0u;
 #pragma unroll
       for (int sg = 0; sg < NSEG; ++sg) {
         if (!((seg_mask >> sg) & 1u)) continue;
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lora_kernel(const float* x,
           xs.y *= mk.y;
           xs.z *= mk.z;
           xs.w *= mk.w;
+          kb |= keep_bits4(mk) << (4 * sg);
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_lora_kernel(const float* x,
           acc[sg][j] = fmaf(xs.w, a.w, fmaf(xs.z, a.z, fmaf(xs.y, a.y, fmaf(xs.x, a.x, acc[sg][j]))));
         }
       }
+      if (keep_bits && drop) keep_bits[(size_t)row * nch + c] = (uint16_t)kb;  // the masks, for the backward
     }
   }
 #pragma unroll
@@ -368,7 +372,7 @@ extern "C" int clipfs_layernorm_fwd_lora_ok(int width, int r, int nseg) {
 extern "C" int clipfs_layernorm_fwd_lora(const float* x, int ldx, const float* gamma, const float* beta, float* y, void* y16,
                                          float* mean, float* rstd, int rows, int width, float eps, const float* A, float* t,
                                          int r, int nseg, unsigned seg_mask, float p, uint64_t seed, uint32_t stream_base,
-                                         uint32_t drow0, void* stream) {
+                                         uint32_t drow0, void* keep_bits, void* stream) {
   CLIPFS_CHECK(check_rows("layernorm_fwd_lora", rows, width));
   CLIPFS_REQUIRE(x && gamma && beta && (y || y16) && A && t, "layernorm_fwd_lora: null pointer");
   CLIPFS_REQUIRE((mean == nullptr) == (rstd == nullptr), "layernorm_fwd_lora: mean and rstd must both be given or both NULL");
@@ -379,18 +383,19 @@ extern "C" int clipfs_layernorm_fwd_lora(const float* x, int ldx, const float* g
   const dim3 grid((rows + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
   _Float16* h = reinterpret_cast<_Float16*>(y16);
+  uint16_t* kb = reinterpret_cast<uint16_t*>(keep_bits);
   switch (r) {
     case 1:
       hipLaunchKernelGGL((layernorm_fwd_lora_kernel<3, 1>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, rows, width,
-                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0);
+                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0, kb);
       break;
     case 2:
       hipLaunchKernelGGL((layernorm_fwd_lora_kernel<3, 2>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, rows, width,
-                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0);
+                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0, kb);
       break;
     default:
       hipLaunchKernelGGL((layernorm_fwd_lora_kernel<3, 4>), grid, dim3(256), 0, st, x, ldx, gamma, beta, y, mean, rstd, rows, width,
-                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0);
+                         eps, h, A, t, seg_mask, p, seed, stream_base, drow0, kb);
       break;
   }
   return launch_status();

@@ -23,8 +23,15 @@ static inline bool qkv_f16(const clipfs_tower* t) {
 }
 
 struct SavedLayout {
-  size_t x_in, stat1, h1, t_qkv, qkv, att, lse, t_o, x_mid, stat2, u, total;
+  size_t x_in, stat1, h1, t_qkv, qkv, att, lse, t_o, x_mid, stat2, u, keep, total;
 };
+
+// the q/k/v adapters' dropout masks travel from the forward to the backward as keep bits (2 bytes per float4 of the
+// LayerNorm output, clipfs_lora_keep_bits_ok) instead of being regenerated from Philox in the dA and dx products
+static inline bool keep_bits_slot(const clipfs_tower* t) {  // the slot exists (layout: independent of the step's seed)
+  return t->lora_r > 0 && t->lora_dropout > 0.f && clipfs_lora_keep_bits_ok(t->width, t->width, t->lora_r, 3);
+}
+static inline bool keep_bits_saved(const clipfs_tower* t) { return keep_bits_slot(t) && t->dropout_seed != 0; }
 
 static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
   const size_t d = t->width, r = t->lora_r > 0 ? t->lora_r : 0;
@@ -43,6 +50,7 @@ static SavedLayout saved_layout(const clipfs_tower* t, size_t M) {
   L.x_mid = o; o += al4(M * d);
   L.stat2 = o; o += al4(2 * M);
   L.u = o;     o += al4(t->weight_format == 2 ? M * 2 * d : M * 4 * d);  // fp16 mode: pre-activation saved as f16
+  L.keep = o;  o += keep_bits_slot(t) ? al4((M * (d / 4) + 1) / 2) : 0;    // uint16 per float4 of h1
   L.total = o;
   return L;
 }
@@ -239,11 +247,12 @@ static int tower_fwd_impl(const clipfs_tower* t, float* x, const int32_t* rows, 
     void* h16 = cx.a16;                                                        // [M, d] halves: ln1 / attention / ln2 / dx
     void* dqkv16 = cx.a16 ? (void*)((char*)cx.a16 + (size_t)M * d * 2) : nullptr;  // [M, 3d] halves
     (void)dqkv16;
+    void* keep = (train && qkv_mask && keep_bits_saved(t)) ? (void*)(sv + SL.keep) : nullptr;
     if (qkv_mask && clipfs_layernorm_fwd_lora_ok(d, r, 3)) {
       // small ranks: the adapter's down-projection rides on the LayerNorm pass (the row is in registers there)
       CLIPFS_CHECK(clipfs_layernorm_fwd_lora(x_in, d, b.ln1_g, b.ln1_b, h1, h16, train ? sv + SL.stat1 : nullptr,
                                              train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, b.lora_a_qkv, t_qkv, r, 3, qkv_mask,
-                                             t->lora_dropout, seed, ds, t->dropout_row0, st));
+                                             t->lora_dropout, seed, ds, t->dropout_row0, keep, st));
     } else {
       if (h16)
         CLIPFS_CHECK(clipfs_layernorm_fwd_f16(x_in, d, b.ln1_g, b.ln1_b, h1, h16, train ? sv + SL.stat1 : nullptr,
@@ -252,7 +261,8 @@ static int tower_fwd_impl(const clipfs_tower* t, float* x, const int32_t* rows, 
         CLIPFS_CHECK(clipfs_layernorm_fwd(x_in, d, b.ln1_g, b.ln1_b, h1, train ? sv + SL.stat1 : nullptr,
                                           train ? sv + SL.stat1 + M : nullptr, M, d, 1e-5f, st));
       if (qkv_mask)
-        CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, t->dropout_row0, st));
+        CLIPFS_CHECK(clipfs_lora_down(h1, b.lora_a_qkv, t_qkv, M, d, r, 3, qkv_mask, t->lora_dropout, seed, ds, t->dropout_row0,
+                                      keep, st));
     }
     const bool q16 = qkv_f16(t);
     CLIPFS_CHECK(gemm(cx, h1, b.w_qkv, b.w_qkv_p, qkv, M, 3 * d, d, b.b_qkv, nullptr, 0, nullptr, nullptr, qkv_mask ? t_qkv : nullptr,
@@ -304,7 +314,8 @@ static int tower_fwd_impl(const clipfs_tower* t, float* x, const int32_t* rows, 
       }
       break;
     }
-    if (lora_o) CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, t->dropout_row0, st));
+    if (lora_o)
+      CLIPFS_CHECK(clipfs_lora_down(att, b.lora_a_o, t_o, M, d, r, 1, 1u, t->lora_dropout, seed, ds + 3, t->dropout_row0, nullptr, st));
     CLIPFS_CHECK(gemm(cx, att, b.w_o, b.w_o_p, x_mid, M, d, d, b.b_o, x_in, 0, nullptr, nullptr, lora_o ? t_o : nullptr, b.lora_b_o, r,
                       1, d, t->lora_scale, st, CHAIN_NONE, att16));
     float* h2 = scratch + SC.h;
@@ -384,7 +395,7 @@ static int tower_bwd_range(const clipfs_tower* t, float* dx, int batch, const fl
     if (lora_o) {
       CLIPFS_REQUIRE(b.g_lora_a_o && b.g_lora_b_o, "tower_bwd: block %d o-LoRA gradient slots missing", l);
       CLIPFS_CHECK(clipfs_lora_bwd(dx, sv + SL.att, sv + SL.t_o, b.lora_a_o, b.lora_b_o, dt, b.g_lora_a_o, b.g_lora_b_o,
-                                   datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, t->dropout_row0, work, st));
+                                   datt, M, d, d, r, 1, 1u, t->lora_scale, t->lora_dropout, seed, ds + 3, t->dropout_row0, nullptr, work, st));
     }
     // (the D_i work vector of the long-sequence kernels lives in the dt scratch slot's neighbour: reuse `dh`, dead here)
     const void* dqkv16_ready = nullptr;
@@ -407,11 +418,11 @@ static int tower_bwd_range(const clipfs_tower* t, float* dx, int batch, const fl
       if (dy16)
         CLIPFS_CHECK(clipfs_lora_bwd_f16dy(dqkv16, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
                                            b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
-                                           t->lora_dropout, seed, ds, t->dropout_row0, work, st));
+                                           t->lora_dropout, seed, ds, t->dropout_row0, keep_bits_saved(t) ? (const void*)(sv + SL.keep) : nullptr, work, st));
       else
         CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
                                      b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
-                                     t->lora_dropout, seed, ds, t->dropout_row0, work, st));
+                                     t->lora_dropout, seed, ds, t->dropout_row0, keep_bits_saved(t) ? (const void*)(sv + SL.keep) : nullptr, work, st));
     }
     if (need_dx) {
       if (h16)
@@ -510,11 +521,12 @@ extern "C" int clipfs_tower_bwd_sparse(const clipfs_tower* t, const float* dxs, 
     if (dy16)
       CLIPFS_CHECK(clipfs_lora_bwd_f16dy(dqkv16, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv,
                                          b.g_lora_b_qkv, need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale,
-                                         t->lora_dropout, t->dropout_seed, ds, t->dropout_row0, work, st));
+                                         t->lora_dropout, t->dropout_seed, ds, t->dropout_row0, keep_bits_saved(t) ? (const void*)(sv + SL.keep) : nullptr,
+                                         work, st));
     else
       CLIPFS_CHECK(clipfs_lora_bwd(dqkv, sv + SL.h1, sv + SL.t_qkv, b.lora_a_qkv, b.lora_b_qkv, dt, b.g_lora_a_qkv, b.g_lora_b_qkv,
                                    need_dx ? dh : nullptr, M, d, d, r, 3, qkv_mask, t->lora_scale, t->lora_dropout,
-                                   t->dropout_seed, ds, t->dropout_row0, work, st));
+                                   t->dropout_seed, ds, t->dropout_row0, keep_bits_saved(t) ? (const void*)(sv + SL.keep) : nullptr, work, st));
   }
   if (!need_dx) return CLIPFS_OK;
   CLIPFS_CHECK(clipfs_layernorm_bwd(dh, sv + SL.x_in, d, b.ln1_g, sv + SL.stat1, sv + SL.stat1 + M, nullptr, dx, d, M, d, st));

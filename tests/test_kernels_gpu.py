@@ -193,6 +193,21 @@ def test_lora_down_and_bwd(dev, p, rows, width, r, nseg):
     _close(dA, A.grad, 2e-4, "lora dA")
     _close(dB, Bm.grad, 2e-4, "lora dB")
     _close(dx, xs.grad, 2e-4, "lora dx")
+    # the forward's masks recorded as keep bits and read back by the backward (matrix-core shapes): the recorded bits are
+    # the oracle's masks, and the backward that reads them gives the bits of the backward that regenerates them
+    from clipfs import _lib
+    if p > 0 and _lib.load().clipfs_lora_keep_bits_ok(width, width, r, nseg):
+        kb = ops.lora_keep_bits(rows, width, dev)
+        t2 = ops.lora_down(D(x), D(A), r, nseg, p=p, seed=seed, stream_base=sb, keep_bits=kb)
+        assert torch.equal(t2, t_gpu)
+        bits = kb.cpu().numpy().view(np.uint16)
+        for s in range(nseg):
+            keep = O.dropout_keep_mask(seed, sb + s, rows, width, p).reshape(rows, width // 4, 4)
+            got = np.stack([(bits >> (4 * s + e)) & 1 for e in range(4)], axis=-1).astype(bool)
+            assert np.array_equal(got, keep), f"keep bits of segment {s}"
+        dA2, dB2, dx2 = torch.zeros_like(dA), torch.zeros_like(dB), torch.zeros_like(dx)
+        ops.lora_bwd(D(dy), D(x), t_gpu, D(A), D(Bm), dA2, dB2, dx=dx2, scale=scale, p=p, seed=seed, stream_base=sb, keep_bits=kb)
+        assert torch.equal(dA2, dA) and torch.equal(dB2, dB) and torch.equal(dx2, dx)
 
 
 @pytest.mark.gpu
@@ -231,6 +246,11 @@ def test_layernorm_with_lora_down(dev, p, rows, width, r, mask):
     # and the stand-alone kernel on the same y (what the backward's masks were tested against)
     t1 = ops.lora_down(y, D(A), r, 3, seg_mask=mask, p=p, seed=seed if p > 0 else 0, stream_base=sb, row0=row0)
     _close(t, t1.double().cpu(), 2e-5, "fused vs stand-alone down")
+    if p > 0 and width % 128 == 0:  # both forwards record the same keep bits
+        kb0, kb1 = ops.lora_keep_bits(rows, width, dev), ops.lora_keep_bits(rows, width, dev)
+        ops.layernorm_fwd_lora(D(x), D(g), D(b), D(A), r, 3, seg_mask=mask, p=p, seed=seed, stream_base=sb, row0=row0, keep_bits=kb0)
+        ops.lora_down(y, D(A), r, 3, seg_mask=mask, p=p, seed=seed, stream_base=sb, row0=row0, keep_bits=kb1)
+        assert torch.equal(kb0, kb1) and kb0.any()
 
 
 def test_dropout_rate(dev):
