@@ -72,6 +72,18 @@ def view_records(width: int, height: int, n_crops: int, scale=(0.5, 1.0), ratio=
     return recs
 
 
+_NORM_CACHE = {}
+
+
+def _norm_constants(dev, mean, std):
+    key = (str(dev), mean, std)
+    hit = _NORM_CACHE.get(key)
+    if hit is None:
+        hit = (torch.tensor(mean, device=dev, dtype=torch.float32), torch.tensor(std, device=dev, dtype=torch.float32))
+        _NORM_CACHE[key] = hit
+    return hit
+
+
 def make_views(image_u8: torch.Tensor, recs: np.ndarray, size: int = 224, mean: Sequence[float] = CLIP_MEAN,
                std: Sequence[float] = CLIP_STD) -> torch.Tensor:
     """image_u8: uint8 [H, W, 3] device tensor -> fp32 [n, 3, size, size] normalised views (one kernel launch)."""
@@ -79,11 +91,12 @@ def make_views(image_u8: torch.Tensor, recs: np.ndarray, size: int = 224, mean: 
     image_u8 = image_u8.contiguous()
     H, W = image_u8.shape[:2]
     dev = image_u8.device
-    r = torch.from_numpy(np.ascontiguousarray(recs, dtype=np.int32)).to(dev)
+    # no host-blocking copy here: a pageable upload waits for everything queued on the current stream, which stalls a
+    # caller that generates views on a side stream under another stream's GEMMs (ood.score_stream)
+    r = torch.from_numpy(np.ascontiguousarray(recs, dtype=np.int32)).pin_memory().to(dev, non_blocking=True)
     n = r.shape[0]
     out = torch.empty(n, 3, size, size, device=dev, dtype=torch.float32)
-    m = torch.tensor(mean, device=dev, dtype=torch.float32)
-    s = torch.tensor(std, device=dev, dtype=torch.float32)
+    m, s = _norm_constants(dev, tuple(float(v) for v in mean), tuple(float(v) for v in std))
     check(_lib.load().clipfs_tta_views(image_u8.data_ptr(), H, W, r.data_ptr(), n, size, m.data_ptr(), s.data_ptr(),
                                        out.data_ptr(), torch.cuda.current_stream().cuda_stream), "tta_views")
     return out

@@ -3,6 +3,7 @@
     cls_acc       ood.py:638-652   accuracy of the base/new decision
     split_ood     ood.py:857-883   per image: 1 centre view + N crops -> encode -> normalise -> MTA ->
                                    argmax <= 372 -> base list, else new list
+    score_stream  ood.py:946-958   the image loop itself as a three-stream pipeline (views | tower | MTA)
 The file writing / dataset loop of the reference stays on the host; here are the batched GPU parts.
 Quirk kept: the split uses ``<= 372`` (ood.py:880) although base classes are 0..373 in classes.txt, and
 cls_acc uses ``< 373`` -- the same boundary.
@@ -52,6 +53,61 @@ def score_views(clip_model, views: torch.Tensor, text_features_cd: torch.Tensor)
     logits, _ = mta_scores(clip_model, views, text_features_cd)
     top5 = ops.topk(logits, 5)
     return top5, top5[:, 0].long() <= BASE_BOUNDARY, logits
+
+
+@torch.no_grad()
+def score_stream(clip_model, sources, text_features_cd: torch.Tensor, n_crops: int = 64, images_per_pass: int = 8,
+                 seed: int = 0, scale=(0.5, 1.0)):
+    """cfg-4 over a LIST of source images (PIL / uint8 arrays / uint8 tensors), ``images_per_pass`` images per tower pass,
+    as a three-stage pipeline on three HIP streams: while the image tower runs group g on the caller's stream, the views
+    of group g + 1 are generated on a second stream (csrc/views.hip: small, memory-bound kernels that fit beside the
+    GEMMs) and the MTA + top-5 of group g - 1 run on a third (one workgroup per image: 8 of 256 CUs for ~3 ms).  The
+    reference overlaps the same stages with DataLoader workers (ood.py:946-958); per group the kernels, seeds (image i
+    draws its crops from ``seed + i``) and results are those of ``score_views`` on ``tta.make_tta_views`` -- only the
+    order in which the GPU sees them changes.  Returns (top5 [n, 5] int32, is_base [n] bool, logits [n, C])."""
+    import tta
+    text = text_features_cd.contiguous().float()
+    dev = text.device
+    n = len(sources)
+    if n == 0:
+        raise ValueError("score_stream: no source images")
+    main = torch.cuda.current_stream(dev)
+    s_views, s_mta = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    groups = [(lo, min(lo + images_per_pass, n)) for lo in range(0, n, images_per_pass)]
+
+    def generate(g):
+        lo, hi = groups[g]
+        with torch.cuda.stream(s_views):
+            v = torch.stack([tta.make_tta_views(sources[i], n_crops, scale=scale, seed=seed + i, device=dev) for i in range(lo, hi)])
+            ev = torch.cuda.Event()
+            ev.record(s_views)
+        return v, ev
+
+    s_views.wait_stream(main)  # the sources may have been uploaded on the caller's stream
+    nxt = generate(0)
+    top5s, logit_list = [], []
+    for g in range(len(groups)):
+        views, ev = nxt
+        if g + 1 < len(groups):
+            nxt = generate(g + 1)  # queued behind group g's views on the side stream: runs under group g's tower pass
+        main.wait_event(ev)
+        views.record_stream(main)
+        n_img, V = views.shape[:2]
+        feats = clip_model.encode_image(views.reshape(n_img * V, *views.shape[2:]))
+        feats = ops.l2norm_fwd(feats.contiguous())
+        evf = torch.cuda.Event()
+        evf.record(main)
+        with torch.cuda.stream(s_mta):
+            s_mta.wait_event(evf)
+            feats.record_stream(s_mta)
+            _, logits = ops.mta(feats.reshape(n_img, V, -1), text)
+            top5s.append(ops.topk(logits, 5))
+            logit_list.append(logits)
+    main.wait_stream(s_mta)
+    for t in top5s + logit_list:
+        t.record_stream(main)
+    top5 = torch.cat(top5s)
+    return top5, top5[:, 0].long() <= BASE_BOUNDARY, torch.cat(logit_list)
 
 
 @torch.no_grad()

@@ -121,6 +121,33 @@ def test_tta_pipeline_views_to_top5(dev, b32):
     assert out["top5"].shape == (n_img, 5)
 
 
+def test_score_stream_is_the_per_group_scoring(dev, b32):
+    """ood.score_stream (views | tower | MTA on three HIP streams, one group ahead) returns exactly what the one-stream
+    loop returns group by group: same kernels, same seeds, only the order in which the GPU sees them differs -- checked
+    over 3 groups (ragged last one) and again on a second call (the side streams are new each time)."""
+    import numpy as np
+    import ood
+    import tta
+    from oracle import clip_oracle as O
+    cfg, sd, model = b32
+    rng = np.random.RandomState(11)
+    srcs = [torch.from_numpy(rng.randint(0, 256, (60 + 7 * i, 90 - 5 * i, 3), dtype=np.uint8)) for i in range(5)]
+    g = torch.Generator().manual_seed(2)
+    text = O.l2_normalize(torch.randn(33, 512, generator=g, dtype=torch.float64)).float().to(dev)
+    want5, wantb, wantl = [], [], []
+    for lo in range(0, 5, 2):
+        views = torch.stack([tta.make_tta_views(srcs[i], 6, seed=40 + i, device=dev) for i in range(lo, min(lo + 2, 5))])
+        t5, ib, lg = ood.score_views(model, views, text)
+        want5.append(t5), wantb.append(ib), wantl.append(lg)
+    want5, wantb, wantl = torch.cat(want5), torch.cat(wantb), torch.cat(wantl)
+    for _ in range(2):
+        t5, ib, lg = ood.score_stream(model, srcs, text, n_crops=6, images_per_pass=2, seed=40)
+        torch.cuda.synchronize()
+        assert torch.equal(t5, want5) and torch.equal(ib, wantb) and torch.equal(lg, wantl)
+    with pytest.raises(ValueError):
+        ood.score_stream(model, [], text)
+
+
 def test_clip_classifier_and_cls_acc(dev, b32):
     import lora_train_vlp as L
     import ood
