@@ -15,7 +15,7 @@ from clipfs import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-M = 32768
+M = int(os.environ.get("STAMPS_M", "32768"))  # STAMPS_M=2048: 96 qkv tiles, i.e. fewer writers at a time than CUs
 for name, N, K, mode in [("qkv  C16 only", 3072, 1024, "c16"), ("out  fp32 C", 1024, 1024, "c32"), ("fc   C16 + aux", 4096, 1024, "fc"),
                          ("proj fp32 C", 1024, 4096, "c32"), ("du   C16 act2", 4096, 1024, "du"), ("sq8192 fp32", 8192, 8192, "sq")]:
     Mi = 8192 if mode == "sq" else M
