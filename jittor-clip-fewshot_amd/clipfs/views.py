@@ -85,8 +85,9 @@ def _norm_constants(dev, mean, std):
 
 
 def make_views(image_u8: torch.Tensor, recs: np.ndarray, size: int = 224, mean: Sequence[float] = CLIP_MEAN,
-               std: Sequence[float] = CLIP_STD) -> torch.Tensor:
-    """image_u8: uint8 [H, W, 3] device tensor -> fp32 [n, 3, size, size] normalised views (one kernel launch)."""
+               std: Sequence[float] = CLIP_STD, out: torch.Tensor = None) -> torch.Tensor:
+    """image_u8: uint8 [H, W, 3] device tensor -> fp32 [n, 3, size, size] normalised views (one kernel launch), written
+    into ``out`` when given (a contiguous fp32 [n, 3, size, size] slice of a caller-owned buffer)."""
     assert image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.dim() == 3 and image_u8.shape[2] == 3
     image_u8 = image_u8.contiguous()
     H, W = image_u8.shape[:2]
@@ -95,7 +96,10 @@ def make_views(image_u8: torch.Tensor, recs: np.ndarray, size: int = 224, mean: 
     # caller that generates views on a side stream under another stream's GEMMs (ood.score_stream)
     r = torch.from_numpy(np.ascontiguousarray(recs, dtype=np.int32)).pin_memory().to(dev, non_blocking=True)
     n = r.shape[0]
-    out = torch.empty(n, 3, size, size, device=dev, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(n, 3, size, size, device=dev, dtype=torch.float32)
+    elif tuple(out.shape) != (n, 3, size, size) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+        raise ValueError(f"make_views: out must be a contiguous fp32 [{n}, 3, {size}, {size}] tensor on {dev}")
     m, s = _norm_constants(dev, tuple(float(v) for v in mean), tuple(float(v) for v in std))
     check(_lib.load().clipfs_tta_views(image_u8.data_ptr(), H, W, r.data_ptr(), n, size, m.data_ptr(), s.data_ptr(),
                                        out.data_ptr(), torch.cuda.current_stream().cuda_stream), "tta_views")

@@ -17,6 +17,7 @@ import torch
 from clipfs import ops
 
 BASE_BOUNDARY = 372
+_SIDE_STREAMS = {}  # device -> (view stream, MTA stream) of score_stream
 
 
 def cls_acc(output: torch.Tensor, target: torch.Tensor, topk: int = 1) -> float:
@@ -72,28 +73,46 @@ def score_stream(clip_model, sources, text_features_cd: torch.Tensor, n_crops: i
     if n == 0:
         raise ValueError("score_stream: no source images")
     main = torch.cuda.current_stream(dev)
-    s_views, s_mta = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    # HIGH priority: HIP maps streams onto a few hardware queues per priority class, and a normal-priority stream can land
+    # on the queue of the caller's stream, which serialises the pipeline without any error
+    # (created once per device and kept: every torch.cuda.Stream() is another stream of torch's pool, i.e. another draw
+    # of the queue mapping)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=-1))
+    s_views, s_mta = _SIDE_STREAMS[key]
     groups = [(lo, min(lo + images_per_pass, n)) for lo in range(0, n, images_per_pass)]
+    V, size = 1 + n_crops, 224
+    # two view buffers owned by this call, written in place by the view kernels (no per-group allocation: a fresh block on
+    # a side stream cannot be recycled before the consumer's stream has passed it, so every group would go to hipMalloc)
+    bufs = [torch.empty(min(images_per_pass, n), V, 3, size, size, device=dev, dtype=torch.float32) for _ in range(min(2, len(groups)))]
+    consumed = [None, None]  # event: the tower pass that read the buffer last has finished
 
     def generate(g):
         lo, hi = groups[g]
+        buf = bufs[g % 2][:hi - lo]
         with torch.cuda.stream(s_views):
-            v = torch.stack([tta.make_tta_views(sources[i], n_crops, scale=scale, seed=seed + i, device=dev) for i in range(lo, hi)])
+            if consumed[g % 2] is not None:
+                s_views.wait_event(consumed[g % 2])
+            for i in range(lo, hi):
+                tta.make_tta_views(sources[i], n_crops, scale=scale, seed=seed + i, size=size, device=dev, out=buf[i - lo])
             ev = torch.cuda.Event()
             ev.record(s_views)
-        return v, ev
+        return buf, ev
 
     s_views.wait_stream(main)  # the sources may have been uploaded on the caller's stream
     nxt = generate(0)
     top5s, logit_list = [], []
     for g in range(len(groups)):
         views, ev = nxt
-        if g + 1 < len(groups):
-            nxt = generate(g + 1)  # queued behind group g's views on the side stream: runs under group g's tower pass
         main.wait_event(ev)
-        views.record_stream(main)
-        n_img, V = views.shape[:2]
-        feats = clip_model.encode_image(views.reshape(n_img * V, *views.shape[2:]))
+        n_img = views.shape[0]
+        feats = clip_model.encode_image(views.reshape(n_img * V, 3, size, size))
+        done = torch.cuda.Event()
+        done.record(main)
+        consumed[g % 2] = done
+        if g + 1 < len(groups):
+            nxt = generate(g + 1)  # on the side stream: runs under group g's tower pass
         feats = ops.l2norm_fwd(feats.contiguous())
         evf = torch.cuda.Event()
         evf.record(main)
@@ -104,6 +123,7 @@ def score_stream(clip_model, sources, text_features_cd: torch.Tensor, n_crops: i
             top5s.append(ops.topk(logits, 5))
             logit_list.append(logits)
     main.wait_stream(s_mta)
+    main.wait_stream(s_views)
     for t in top5s + logit_list:
         t.record_stream(main)
     top5 = torch.cat(top5s)

@@ -10,7 +10,7 @@ import torch
 from clipfs import ops
 
 
-def make_tta_views(image, n_crops: int = 512, scale=(0.5, 1.0), seed: int = 0, size: int = 224, device=None):
+def make_tta_views(image, n_crops: int = 512, scale=(0.5, 1.0), seed: int = 0, size: int = 224, device=None, out=None):
     """The 1 + n_crops views of one image as a device tensor [1 + n_crops, 3, size, size] (view 0 = the centre
     preprocess, the rest RandomResizedCrop(scale) + flip), generated ON THE GPU from the uint8 image
     (csrc/views.hip, pixel-exact with PIL).  Replaces the reference's CPU worker loop ood.py:946-958 /
@@ -26,7 +26,7 @@ def make_tta_views(image, n_crops: int = 512, scale=(0.5, 1.0), seed: int = 0, s
     image = image.to(device)
     H, W = image.shape[:2]
     recs = views.view_records(W, H, n_crops, scale=scale, seed=seed, size=size)
-    return views.make_views(image, recs, size)
+    return views.make_views(image, recs, size, out=out)
 
 
 @torch.no_grad()
