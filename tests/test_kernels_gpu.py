@@ -157,9 +157,11 @@ def test_attention(dev, B, L, H, causal):
 # ------------------------------------------------------------------ LoRA
 @pytest.mark.parametrize("p", [0.0, 0.25])
 @pytest.mark.parametrize("rows,width,r,nseg", [(333, 128, 4, 3), (200, 256, 16, 3), (77, 128, 16, 1), (150, 192, 2, 3),
-                                                (1100, 128, 8, 3), (90, 384, 1, 1)])
+                                                (1100, 128, 8, 3), (90, 384, 1, 1), (257, 512, 4, 3), (130, 768, 12, 3),
+                                                (45, 1024, 16, 3), (61, 256, 3, 1)])
 def test_lora_down_and_bwd(dev, p, rows, width, r, nseg):
-    """width % 128 == 0 runs the fp32-MFMA kernels (lora_mfma.hip), 192 the one-wave-per-row kernels (lora.hip)."""
+    """width % 128 == 0 runs the fp32-MFMA kernels (lora_mfma.hip), 192 the one-wave-per-row kernels (lora.hip); the
+    512 / 768 / 1024 cases are the towers' own widths."""
     from clipfs import ops
     from oracle import clip_oracle as O
     seed, sb = 0x1234ABCD5, 7
