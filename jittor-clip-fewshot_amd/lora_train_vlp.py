@@ -667,15 +667,11 @@ class LoRATrainer:
         main.wait_stream(side)
         return loss_sum, correct, logits
 
-    _SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}  # one per device for every trainer of the process (HIP maps
-    # streams onto a handful of hardware queues: a fresh stream per trainer ends up sharing a queue with another one)
-
     def _side_stream(self):
-        key = str(self.model.device)
-        if key not in LoRATrainer._SIDE_STREAMS:
-            prio = int(os.environ.get("CLIPFS_SIDE_STREAM_PRIORITY", "-1"))
-            LoRATrainer._SIDE_STREAMS[key] = torch.cuda.Stream(device=self.model.device, priority=prio)
-        return LoRATrainer._SIDE_STREAMS[key]
+        # one per device for everything in the process (clipfs/streams.py: HIP maps streams onto a handful of hardware
+        # queues, and a fresh stream per user ends up sharing a queue with another one)
+        from clipfs import streams
+        return streams.side_stream(self.model.device)
 
     def optimizer_step(self):
         from clipfs import dist as D

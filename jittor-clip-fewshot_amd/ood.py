@@ -17,7 +17,6 @@ import torch
 from clipfs import ops
 
 BASE_BOUNDARY = 372
-_SIDE_STREAMS = {}  # device -> (view stream, MTA stream) of score_stream
 
 
 def cls_acc(output: torch.Tensor, target: torch.Tensor, topk: int = 1) -> float:
@@ -60,9 +59,9 @@ def score_views(clip_model, views: torch.Tensor, text_features_cd: torch.Tensor)
 def score_stream(clip_model, sources, text_features_cd: torch.Tensor, n_crops: int = 64, images_per_pass: int = 8,
                  seed: int = 0, scale=(0.5, 1.0)):
     """cfg-4 over a LIST of source images (PIL / uint8 arrays / uint8 tensors), ``images_per_pass`` images per tower pass,
-    as a three-stage pipeline on three HIP streams: while the image tower runs group g on the caller's stream, the views
-    of group g + 1 are generated on a second stream (csrc/views.hip: small, memory-bound kernels that fit beside the
-    GEMMs) and the MTA + top-5 of group g - 1 run on a third (one workgroup per image: 8 of 256 CUs for ~3 ms).  The
+    as a three-stage pipeline: while the image tower runs group g on the caller's stream, the views of group g + 1
+    (csrc/views.hip: small, memory-bound kernels that fit beside the GEMMs) and the MTA + top-5 of group g - 1 (one
+    workgroup per image: 8 of 256 CUs for ~3 ms) run on the process's high-priority side stream.  The
     reference overlaps the same stages with DataLoader workers (ood.py:946-958); per group the kernels, seeds (image i
     draws its crops from ``seed + i``) and results are those of ``score_views`` on ``tta.make_tta_views`` -- only the
     order in which the GPU sees them changes.  Returns (top5 [n, 5] int32, is_base [n] bool, logits [n, C])."""
@@ -73,14 +72,11 @@ def score_stream(clip_model, sources, text_features_cd: torch.Tensor, n_crops: i
     if n == 0:
         raise ValueError("score_stream: no source images")
     main = torch.cuda.current_stream(dev)
-    # HIGH priority: HIP maps streams onto a few hardware queues per priority class, and a normal-priority stream can land
-    # on the queue of the caller's stream, which serialises the pipeline without any error
-    # (created once per device and kept: every torch.cuda.Stream() is another stream of torch's pool, i.e. another draw
-    # of the queue mapping)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev, priority=-1))
-    s_views, s_mta = _SIDE_STREAMS[key]
+    # ONE side stream for both overlapped stages, and the same one the trainer uses (clipfs/streams.py: every further
+    # stream is another draw of HIP's stream -> hardware-queue mapping, and an unlucky one serialises somebody's overlap
+    # without any error).  Order on it per group: views of g + 1, then MTA of g (which waits for the tower pass of g).
+    from clipfs import streams
+    s_views = s_mta = streams.side_stream(dev)
     groups = [(lo, min(lo + images_per_pass, n)) for lo in range(0, n, images_per_pass)]
     V, size = 1 + n_crops, 224
     # two view buffers owned by this call, written in place by the view kernels (no per-group allocation: a fresh block on
