@@ -40,6 +40,28 @@ def test_gemm_plain(dev, M, N, K):
     _close(out, a @ b.t(), 2e-5 * math.sqrt(K) * 4, f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 768), (12800, 2304, 256), (12801, 768, 512), (31031, 512, 128)])
+def test_gemm_full_size_rows(dev, M, N, K):
+    """The stand-alone GEMM at the row counts the bench times (12 800 image-token rows, 31 031 caption-token rows, one
+    ragged): several rounds of 64 x 128 tiles over the CUs in the XCD-contiguous super-tile order, against an fp64 product,
+    with every epilogue option, bitwise reproducible."""
+    from clipfs import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g) * K ** -0.5
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ad, bd = a.to(dev), b.to(dev)
+    want = a.double() @ b.double().t()
+    out = ops.gemm_nt(ad, bd)
+    _close(out, want, 2e-5 * math.sqrt(K) * 4, "full-size plain")
+    assert torch.equal(ops.gemm_nt(ad, bd), out)
+    u = torch.empty(M, N, device=dev)
+    out = ops.gemm_nt(ad, bd, bias=bias.to(dev), residual=res.to(dev), act=1, aux_out=u)
+    pre = want + bias.double()
+    _close(u, pre, 1e-4, "full-size pre-activation")
+    _close(out, pre * torch.sigmoid(1.702 * pre) + res.double(), 1e-4, "full-size bias + gelu + residual")
+
+
 def test_gemm_asymmetric_layout(dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide section 3)."""
     from clipfs import ops
